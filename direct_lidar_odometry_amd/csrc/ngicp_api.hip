@@ -1,0 +1,1096 @@
+// C-ABI implementation (include/ngicp.h) — host driver for the HIP kernels.
+// One handle == one nano_gicp::NanoGICP instance (/root/reference/include/nano_gicp/nano_gicp.hpp:58-137).
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include "../../include/ngicp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ngicp_pass.h"
+
+using namespace ngk;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HipError {
+  hipError_t code;
+  const char* what;
+  const char* file;
+  int line;
+};
+
+#define HIP_TRY(expr)                                          \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) throw HipError{_e, #expr, __FILE__, __LINE__}; \
+  } while (0)
+
+struct ArgError {
+  int code;
+  std::string msg;
+};
+
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// grow-only device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIP_TRY(hipMalloc(&p, want));
+    cap = want;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+// An uploaded, cell-sorted, indexed cloud.  Shared between handles (odom.cc:525) and between the
+// source/target slots (swapSourceAndTarget) through shared_ptr.
+struct DeviceCloud {
+  size_t n = 0;
+  DevBuf sorted;      // float4[n]
+  DevBuf perm;        // int[n]    sorted position -> original index
+  DevBuf inv_perm;    // int[n]    original index -> sorted position (lazily built)
+  bool has_inv = false;
+  DevBuf cell_start;  // int[ncells + 1]
+  Grid grid{};
+  double build_ms = 0.0;
+};
+
+// Covariances, packed symmetric FP64 [n][6], stored in the sorted order of `order`.
+struct CovSet {
+  std::shared_ptr<DevBuf> data;
+  size_t n = 0;
+  std::shared_ptr<DeviceCloud> order;
+  void clear() {
+    data.reset();
+    order.reset();
+    n = 0;
+  }
+};
+
+struct Slot {
+  std::shared_ptr<DeviceCloud> dev;
+  const float* host = nullptr;  // pending (registered, not yet uploaded) cloud
+  size_t n = 0;
+  size_t stride = 0;
+  uint64_t identity = 0;
+  bool present = false;
+  void clear() {
+    dev.reset();
+    host = nullptr;
+    n = stride = 0;
+    identity = 0;
+    present = false;
+  }
+};
+
+struct Params {
+  int k = 20;                                                       // impl/nano_gicp_impl.hpp:57
+  double max_corr_dist = (double)std::numeric_limits<float>::max(); // :59
+  int max_iter = 64;                                                // impl/lsq_registration_impl.hpp:52
+  double trans_eps = 5e-4;                                          // :54
+  double rot_eps = 2e-3;                                            // :53
+  int optimizer = NGICP_OPT_LEVENBERG_MARQUARDT;                    // :56
+  int lm_max_iter = 10;                                             // :58
+  double lm_init_lambda_factor = 1e-9;                              // :59
+  int regularization = NGICP_REG_PLANE;                             // impl/nano_gicp_impl.hpp:61
+  int num_threads = 0;
+};
+
+}  // namespace
+
+struct ngicp {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_poll[2] = {nullptr, nullptr};
+  std::string err;
+  Params p;
+  double voxel_size = 0.0;  // 0 = auto
+  int lanes_per_query = 0;  // 0 = auto
+  double target_occupancy = 8.0;
+  int max_blocks = 1024;    // pass-kernel grid cap: 4 blocks x 256 CUs
+  bool profiling = false;
+
+  Slot src, tgt;
+  CovSet src_covs, tgt_covs;
+
+  // workspaces
+  DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
+  DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
+  int* h_poll = nullptr;  // pinned: done flags
+  int hook_valid = 0;     // linearize hook has produced correspondences
+
+  // results of the last align
+  float final_T[16];
+  double final_hessian[36];
+  int converged = 0, nr_iterations = 0;
+  std::vector<double> trace_host;
+  ngicp_stats stats{};
+
+  // sharded stepping
+  bool sharded_active = false;
+};
+
+namespace {
+
+int pick_blocks(size_t work_items, int per_block, int max_blocks) {
+  size_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (size_t)max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// Index build
+// ------------------------------------------------------------------------------------------
+Grid make_grid(const float mn[3], const float mx[3], double h, int max_cells) {
+  Grid g{};
+  double ext[3];
+  for (int d = 0; d < 3; ++d) ext[d] = std::max(0.0, (double)mx[d] - (double)mn[d]);
+  for (;;) {
+    double nx = std::floor(ext[0] / h) + 1, ny = std::floor(ext[1] / h) + 1, nz = std::floor(ext[2] / h) + 1;
+    if (nx * ny * nz <= (double)max_cells) {
+      g.nx = (int)nx;
+      g.ny = (int)ny;
+      g.nz = (int)nz;
+      break;
+    }
+    h *= 1.26;
+  }
+  g.ox = mn[0];
+  g.oy = mn[1];
+  g.oz = mn[2];
+  g.h = (float)h;
+  g.inv_h = 1.0f / g.h;
+  g.ncells = g.nx * g.ny * g.nz;
+  double span = std::max(ext[0], std::max(ext[1], ext[2]));
+  g.slack = (float)(1e-3 * h + 4e-6 * (span + std::fabs(mn[0]) + std::fabs(mn[1]) + std::fabs(mn[2])));
+  return g;
+}
+
+void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_host /*[1] sum count^2, or null*/) {
+  const Grid& g = dc.grid;
+  h->counts.ensure((size_t)(g.ncells + 1) * sizeof(int));
+  HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(g.ncells + 1) * sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_cell_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), n, g, h->keys.as<int>(), h->counts.as<int>());
+  const int ntiles = (g.ncells + kScanTile - 1) / kScanTile;
+  h->tile_sums.ensure((size_t)ntiles * sizeof(int));
+  h->tile_sq.ensure((size_t)ntiles * sizeof(unsigned long long));
+  dc.cell_start.ensure((size_t)(g.ncells + 1) * sizeof(int));
+  unsigned long long* tsq = occ_host ? h->tile_sq.as<unsigned long long>() : nullptr;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), g.ncells, h->tile_sums.as<int>(), tsq);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)tsq,
+                     h->occ.as<unsigned long long>());
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), g.ncells, h->tile_sums.as<int>(), dc.cell_start.as<int>());
+  if (occ_host) {
+    HIP_TRY(hipMemcpyAsync(occ_host, h->occ.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+}
+
+std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t n, size_t stride) {
+  if (n == 0) throw ArgError{NGICP_ERR_ARG, "empty cloud"};
+  if (n > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "cloud too large for int indices"};
+  if (stride < 12 || (stride % 4) != 0) throw ArgError{NGICP_ERR_ARG, "stride_bytes must be a multiple of 4 and >= 12"};
+  auto dc = std::make_shared<DeviceCloud>();
+  dc->n = n;
+  const int ni = (int)n;
+  const double t0 = now_ms();
+  const size_t raw_bytes = (n - 1) * stride + 12;
+  h->raw.ensure(raw_bytes);
+  HIP_TRY(hipMemcpyAsync(h->raw.p, xyz, raw_bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stats.upload_ms = now_ms() - t0;
+
+  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+  h->unsorted.ensure(n * sizeof(float4));
+  h->keys.ensure(n * sizeof(int));
+  h->tmp.ensure(n * sizeof(float4));
+  const int bbox_blocks = pick_blocks(n, 1024, 512);
+  h->bbox.ensure((size_t)bbox_blocks * 6 * sizeof(float));
+  h->occ.ensure(2 * sizeof(unsigned long long));
+  hipLaunchKernelGGL(k_unpack_bbox, dim3(bbox_blocks), dim3(256), 0, h->stream, h->raw.as<unsigned char>(), stride, ni, h->unsorted.as<float4>(), h->bbox.as<float>());
+  std::vector<float> bb((size_t)bbox_blocks * 6);
+  HIP_TRY(hipMemcpyAsync(bb.data(), h->bbox.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int b = 0; b < bbox_blocks; ++b)
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = std::min(mn[d], bb[(size_t)b * 6 + d]);
+      mx[d] = std::max(mx[d], bb[(size_t)b * 6 + 3 + d]);
+    }
+  for (int d = 0; d < 3; ++d)
+    if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || mn[d] > mx[d]) throw ArgError{NGICP_ERR_ARG, "cloud contains non-finite coordinates"};
+  const int max_cells = 1 << 25;
+  double hh;
+  const bool auto_h = !(h->voxel_size > 0.0);
+  if (!auto_h) {
+    hh = h->voxel_size;
+  } else {
+    double vol = 1.0;
+    for (int d = 0; d < 3; ++d) vol *= std::max(0.05, (double)mx[d] - (double)mn[d]);
+    hh = std::cbrt(vol / (double)n) * 1.5;  // first guess; refined from measured occupancy below
+    hh = std::max(hh, 0.02);
+  }
+  dc->grid = make_grid(mn, mx, hh, max_cells);
+  unsigned long long occ = 0;
+  count_and_scan(h, *dc, ni, auto_h ? &occ : nullptr);
+  if (auto_h) {
+    // refine the voxel edge until the mean occupancy seen by a random point (sum c^2 / n) is near the target
+    for (int it = 0; it < 4; ++it) {
+      const double lam = (double)occ / (double)n;
+      const double ratio = h->target_occupancy / std::max(lam, 1.0);
+      if (ratio > 0.75 && ratio < 1.33) break;
+      double scale = std::pow(ratio, 1.0 / 1.5);
+      scale = std::min(4.0, std::max(0.25, scale));
+      hh = std::max(0.01, (double)dc->grid.h * scale);
+      dc->grid = make_grid(mn, mx, hh, max_cells);
+      count_and_scan(h, *dc, ni, &occ);
+    }
+  }
+  const Grid& g = dc->grid;
+  h->fill.ensure((size_t)(g.ncells + 1) * sizeof(int));
+  HIP_TRY(hipMemsetAsync(h->fill.p, 0, (size_t)(g.ncells + 1) * sizeof(int), h->stream));
+  dc->sorted.ensure(n * sizeof(float4));
+  dc->perm.ensure(n * sizeof(int));
+  hipLaunchKernelGGL(k_cell_scatter, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), h->keys.as<int>(), ni, dc->cell_start.as<int>(),
+                     h->fill.as<int>(), h->tmp.as<float4>());
+  hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cell_start.as<int>(), dc->sorted.as<float4>(),
+                     dc->perm.as<int>());
+  HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev_b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+  dc->build_ms = ms;
+  h->stats.index_build_ms = ms;
+  HIP_TRY(hipGetLastError());
+  return dc;
+}
+
+void ensure_inv_perm(ngicp* h, DeviceCloud& dc) {
+  if (dc.has_inv) return;
+  dc.inv_perm.ensure(dc.n * sizeof(int));
+  hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)((dc.n + 255) / 256)), dim3(256), 0, h->stream, dc.perm.as<int>(), (int)dc.n, dc.inv_perm.as<int>());
+  dc.has_inv = true;
+}
+
+void ensure_slot_ready(ngicp* h, Slot& s, const char* what) {
+  if (!s.present) throw ArgError{NGICP_ERR_STATE, std::string("no ") + what + " cloud set"};
+  if (s.dev) return;
+  if (!s.host) throw ArgError{NGICP_ERR_STATE, std::string(what) + " cloud has no data"};
+  s.dev = upload_and_index(h, s.host, s.n, s.stride);
+}
+
+// ------------------------------------------------------------------------------------------
+// Covariances
+// ------------------------------------------------------------------------------------------
+template <int K>
+void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out) {
+  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + 127) / 128)), dim3(128), 0, h->stream, dc.sorted.as<float4>(), dc.cell_start.as<int>(), dc.grid, (int)dc.n, k,
+                     reg, out);
+}
+
+void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
+  ensure_slot_ready(h, slot, what);
+  DeviceCloud& dc = *slot.dev;
+  const int k = h->p.k;
+  if (k <= 0) throw ArgError{NGICP_ERR_ARG, "k must be positive"};
+  if (k > 32 || (size_t)k > dc.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
+  auto buf = std::make_shared<DevBuf>();
+  buf->ensure(dc.n * 6 * sizeof(double));
+  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+  const int reg = h->p.regularization;
+  if (k <= 10)
+    launch_cov<10>(h, dc, k, reg, buf->as<double>());
+  else if (k <= 20)
+    launch_cov<20>(h, dc, k, reg, buf->as<double>());
+  else
+    launch_cov<32>(h, dc, k, reg, buf->as<double>());
+  HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev_b));
+  HIP_TRY(hipGetLastError());
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+  h->stats.covariance_ms = ms;
+  cs.data = buf;
+  cs.n = dc.n;
+  cs.order = slot.dev;
+}
+
+// make `cs` usable with cloud `dc` (same n): returns device pointer to [n][6] in dc's sorted order
+const double* covs_for(ngicp* h, CovSet& cs, const std::shared_ptr<DeviceCloud>& dc) {
+  if (cs.order.get() == dc.get()) return cs.data->as<double>();
+  // covariances are logically indexed by ORIGINAL point index (the reference's vector index):
+  // re-order from the donor cloud's sorted order to this cloud's sorted order
+  ensure_inv_perm(h, *cs.order);
+  auto buf = std::make_shared<DevBuf>();
+  buf->ensure(dc->n * 6 * sizeof(double));
+  hipLaunchKernelGGL(k_covs_reorder, dim3((unsigned)((dc->n + 255) / 256)), dim3(256), 0, h->stream, cs.data->as<double>(), cs.order->inv_perm.as<int>(), dc->perm.as<int>(),
+                     (int)dc->n, buf->as<double>());
+  cs.data = buf;
+  cs.order = dc;
+  return cs.data->as<double>();
+}
+
+void get_covs(ngicp* h, CovSet& cs, double* out) {
+  if (cs.n == 0) return;
+  h->scratch16.ensure(cs.n * 16 * sizeof(double));
+  hipLaunchKernelGGL(k_covs_expand, dim3((unsigned)((cs.n + 255) / 256)), dim3(256), 0, h->stream, cs.data->as<double>(), cs.order->perm.as<int>(), (int)cs.n,
+                     h->scratch16.as<double>());
+  HIP_TRY(hipMemcpyAsync(out, h->scratch16.p, cs.n * 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+}
+
+void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, const char* what) {
+  if (n == 0) {
+    cs.clear();
+    return;
+  }
+  // The reference accepts any vector; sizes are reconciled at align() (impl/nano_gicp_impl.hpp:163-168).
+  // The packed image needs an ordering cloud: require the slot's cloud with the same size.
+  if (!slot.present || slot.n != n) throw ArgError{NGICP_ERR_STATE, std::string("set covariances: ") + what + " cloud missing or of different size"};
+  ensure_slot_ready(h, slot, what);
+  h->scratch16.ensure(n * 16 * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(h->scratch16.p, in, n * 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  auto buf = std::make_shared<DevBuf>();
+  buf->ensure(n * 6 * sizeof(double));
+  hipLaunchKernelGGL(k_covs_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->scratch16.as<double>(), slot.dev->perm.as<int>(), (int)n, buf->as<double>());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  cs.data = buf;
+  cs.n = n;
+  cs.order = slot.dev;
+}
+
+// ------------------------------------------------------------------------------------------
+// Registration loop
+// ------------------------------------------------------------------------------------------
+int auto_lanes(size_t n_src) {
+  // fill the chip (256 CUs x 2048 threads): cooperate more when there are few queries
+  if (n_src >= 1000000) return 2;
+  if (n_src >= 400000) return 4;
+  return 8;
+}
+
+template <int G>
+void launch_pass_t(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_gicp_pass<G>, dim3(nblocks), dim3(256), 0, s, a);
+}
+
+void launch_pass(ngicp* h, const PassArgs& a, int lanes, int nblocks, hipStream_t s) {
+  switch (lanes) {
+    case 1: launch_pass_t<1>(h, a, nblocks, s); break;
+    case 2: launch_pass_t<2>(h, a, nblocks, s); break;
+    case 4: launch_pass_t<4>(h, a, nblocks, s); break;
+    case 16: launch_pass_t<16>(h, a, nblocks, s); break;
+    default: launch_pass_t<8>(h, a, nblocks, s); break;
+  }
+}
+
+struct LoopCtx {
+  PassArgs pa;
+  SolveArgs sa;
+  int lanes;
+  int nblocks;
+};
+
+void prepare_loop(ngicp* h, LoopCtx& c) {
+  ensure_slot_ready(h, h->src, "source");
+  ensure_slot_ready(h, h->tgt, "target");
+  // lazy covariances (impl/nano_gicp_impl.hpp:163-168)
+  if (h->src_covs.n != h->src.dev->n) compute_covs(h, h->src, h->src_covs, "source");
+  if (h->tgt_covs.n != h->tgt.dev->n) compute_covs(h, h->tgt, h->tgt_covs, "target");
+  DeviceCloud& S = *h->src.dev;
+  DeviceCloud& T = *h->tgt.dev;
+  const size_t n = S.n;
+  for (int i = 0; i < 2; ++i) {
+    h->corr[i].ensure(n * sizeof(int));
+    h->mahal[i].ensure(n * 6 * sizeof(double));
+  }
+  int lanes = h->lanes_per_query > 0 ? h->lanes_per_query : auto_lanes(n);
+  if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16) lanes = 8;
+  const int groups_per_block = 256 / lanes;
+  (void)groups_per_block;
+  const int groups = 64 / lanes;
+  const int batch = groups > 16 ? groups : 16;  // queries per wave batch (k_gicp_pass)
+  int nblocks = pick_blocks((n + batch - 1) / batch, 4, h->max_blocks);
+  h->partials.ensure((size_t)kNumSlots * h->max_blocks * sizeof(double));
+  h->state.ensure(sizeof(LmState));
+  const int max_rows = std::max(1, h->p.max_iter) * std::max(1, h->p.lm_max_iter) + 1;
+  h->trace.ensure((size_t)max_rows * kTraceCols * sizeof(double));
+  h->sums.ensure(kPartialStride * sizeof(double));
+
+  PassArgs& a = c.pa;
+  a.src = S.sorted.as<float4>();
+  a.cov_src = covs_for(h, h->src_covs, h->src.dev);
+  a.n_src = (int)n;
+  a.tgt = T.sorted.as<float4>();
+  a.tgt_cell_start = T.cell_start.as<int>();
+  a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
+  a.grid = T.grid;
+  for (int i = 0; i < 2; ++i) {
+    a.corr[i] = h->corr[i].as<int>();
+    a.mahal[i] = h->mahal[i].as<double>();
+  }
+  a.gate_sq = h->p.max_corr_dist * h->p.max_corr_dist;
+  {
+    float f = (float)a.gate_sq;  // may round down or overflow to inf
+    if ((double)f < a.gate_sq) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    a.gate_sq_f = f;
+  }
+  a.st = h->state.as<LmState>();
+  a.partials = h->partials.as<double>();
+  a.partial_pitch = h->max_blocks;
+  a.mode = 3;
+
+  SolveArgs& s = c.sa;
+  s.st = a.st;
+  s.cfg.max_iterations = h->p.max_iter;
+  s.cfg.lm_max_iterations = h->p.lm_max_iter;
+  s.cfg.optimizer = h->p.optimizer;
+  s.cfg.rot_eps = h->p.rot_eps;
+  s.cfg.trans_eps = h->p.trans_eps;
+  s.cfg.lm_init_lambda_factor = h->p.lm_init_lambda_factor;
+  s.partials = a.partials;
+  s.nblocks = nblocks;
+  s.pitch = h->max_blocks;
+  s.trace = h->trace.as<double>();
+  s.max_trace_rows = max_rows;
+  s.mode = 0;
+  s.sums_out = nullptr;
+  c.lanes = lanes;
+  c.nblocks = nblocks;
+  h->stats.lanes_per_query = lanes;
+  h->stats.voxel_size = T.grid.h;
+  h->stats.grid_dims[0] = T.grid.nx;
+  h->stats.grid_dims[1] = T.grid.ny;
+  h->stats.grid_dims[2] = T.grid.nz;
+}
+
+void init_state_from_pose(LmState& st, const Pose& x0) {
+  std::memset(&st, 0, sizeof(st));
+  st.hot.x0 = x0;
+  st.hot.xi = x0;
+  pose_identity(st.hot.delta);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) st.xi_f[r * 4 + c] = (float)x0.R[r * 3 + c];
+    st.xi_f[r * 4 + 3] = (float)x0.t[r];
+  }
+  st.hot.lambda = -1.0;  // impl/lsq_registration_impl.hpp:92
+  st.hot.nu = 2.0;
+  for (int i = 0; i < 6; ++i) st.final_hessian[i * 6 + i] = 1.0;
+}
+
+Pose pose_from_colmajor_f(const float m[16]) {  // Isometry3d(guess.cast<double>()), impl/lsq_registration_impl.hpp:90
+  Pose p;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) p.R[r * 3 + c] = (double)m[c * 4 + r];
+    p.t[r] = (double)m[12 + r];
+  }
+  return p;
+}
+Pose pose_from_colmajor_d(const double m[16]) {
+  Pose p;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) p.R[r * 3 + c] = m[c * 4 + r];
+    p.t[r] = m[12 + r];
+  }
+  return p;
+}
+void pose_to_colmajor_f(const Pose& p, float m[16]) {  // x0.cast<float>().matrix(), :113
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) m[c * 4 + r] = (float)p.R[r * 3 + c];
+    m[12 + r] = (float)p.t[r];
+    m[r * 4 + 3] = 0.f;
+  }
+  m[15] = 1.f;
+}
+
+void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride) {
+  const double t_begin = now_ms();
+  h->hook_valid = 0;
+  h->converged = 0;
+  h->nr_iterations = 0;
+  const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::memcpy(h->final_T, I, sizeof(I));  // PCL align(): final_transformation_ = Identity before computeTransformation
+  LoopCtx c;
+  prepare_loop(h, c);
+  LmState st;
+  init_state_from_pose(st, pose_from_colmajor_f(guess));
+  c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
+  if (const char* dbg = std::getenv("NGICP_DEBUG_MODE")) c.pa.mode |= (std::atoi(dbg) & (8 | 16));  // timing experiments only
+  if (h->p.max_iter <= 0) st.hot.done = 1;
+  HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+
+  const long max_passes = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? (long)h->p.max_iter : (long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1;
+  const int chunk = 4;
+  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+  long launched = 0;
+  int slot = 0;
+  bool pending[2] = {false, false};
+  LmState* dst = h->state.as<LmState>();
+  bool finished = (h->p.max_iter <= 0);
+  while (!finished && launched < max_passes) {
+    // one chunk ahead: before enqueuing chunk c+2, look at the flag recorded after chunk c
+    if (pending[slot]) {
+      HIP_TRY(hipEventSynchronize(h->ev_poll[slot]));
+      pending[slot] = false;
+      if (h->h_poll[slot]) {
+        finished = true;
+        break;
+      }
+    }
+    for (int i = 0; i < chunk && launched < max_passes; ++i, ++launched) {
+      launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+      hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
+    }
+    HIP_TRY(hipMemcpyAsync(&h->h_poll[slot], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_poll[slot], h->stream));
+    pending[slot] = true;
+    slot ^= 1;
+  }
+  HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+  HIP_TRY(hipMemcpyAsync(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipGetLastError());
+  float loop_ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&loop_ms, h->ev_a, h->ev_b));
+
+  pose_to_colmajor_f(st.hot.x0, h->final_T);
+  h->converged = st.hot.converged;
+  h->nr_iterations = st.hot.nr_iterations;
+  for (int r = 0; r < 6; ++r)
+    for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.final_hessian[r * 6 + cc];
+  if (st.hot.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // impl/lsq_registration_impl.hpp:106
+  h->trace_host.resize((size_t)st.hot.n_trace * kTraceCols);
+  if (st.hot.n_trace) HIP_TRY(hipMemcpy(h->trace_host.data(), h->trace.p, h->trace_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+
+  if (aligned) {
+    const size_t n = h->src.dev->n;
+    h->tfinal.ensure(16 * sizeof(float));
+    h->out_xyz.ensure(n * 3 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->tfinal.p, h->final_T, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_transform_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->src.dev->sorted.as<float4>(), (int)n, h->tfinal.as<float>(),
+                       h->out_xyz.as<float>());
+    if (out_stride == 12) {
+      HIP_TRY(hipMemcpyAsync(aligned, h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    } else {
+      std::vector<float> tmp(n * 3);
+      HIP_TRY(hipMemcpyAsync(tmp.data(), h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      for (size_t i = 0; i < n; ++i) {
+        float* o = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(aligned) + i * out_stride);
+        o[0] = tmp[i * 3 + 0];
+        o[1] = tmp[i * 3 + 1];
+        o[2] = tmp[i * 3 + 2];
+      }
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  ngicp_stats& s = h->stats;
+  s.loop_ms = loop_ms;
+  s.passes = st.hot.passes;
+  s.outer_iterations = st.hot.nr_iterations + 1;
+  s.lm_trials = st.hot.n_trace;
+  s.mean_candidates = st.hot.passes > 0 ? st.hot.cand_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
+  s.valid_fraction = st.hot.passes > 0 ? st.hot.valid_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
+  s.pass_ms_total = loop_ms;
+  s.align_ms = now_ms() - t_begin;
+}
+
+template <class F>
+int guarded(ngicp* h, F&& f) {
+  if (!h) return NGICP_ERR_ARG;
+  try {
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) throw HipError{e, "hipSetDevice", __FILE__, __LINE__};
+    f();
+    return NGICP_OK;
+  } catch (const HipError& e) {
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "HIP error %d (%s) in `%s` at %s:%d", (int)e.code, hipGetErrorString(e.code), e.what, e.file, e.line);
+    h->err = buf;
+    (void)hipGetLastError();
+    return NGICP_ERR_HIP;
+  } catch (const ArgError& e) {
+    h->err = e.msg;
+    return e.code;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return NGICP_ERR_ARG;
+  } catch (...) {
+    h->err = "unknown error";
+    return NGICP_ERR_ARG;
+  }
+}
+
+int set_cloud(ngicp* h, Slot& slot, const float* xyz, size_t n, size_t stride, uint64_t identity, bool build_now) {
+  return guarded(h, [&] {
+    if (!xyz && n) throw ArgError{NGICP_ERR_ARG, "null cloud pointer"};
+    if (identity != 0 && slot.present && slot.identity == identity) return;  // pointer-identity early-out
+    slot.clear();
+    slot.present = true;
+    slot.host = xyz;
+    slot.n = n;
+    slot.stride = stride;
+    slot.identity = identity;
+    if (build_now) slot.dev = upload_and_index(h, xyz, n, stride);
+  });
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* ngicp_version(void) { return "ngicp-hip 0.1 (gfx950)"; }
+
+int ngicp_create(int device, ngicp_t** out) {
+  if (!out) return NGICP_ERR_ARG;
+  *out = nullptr;
+  try {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+      g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+      (void)hipGetLastError();
+      return NGICP_ERR_HIP;
+    }
+    if (device < 0 || device >= count) {
+      g_create_error = "device index out of range";
+      return NGICP_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<ngicp> h(new ngicp);
+    h->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev_a));
+    HIP_TRY(hipEventCreate(&h->ev_b));
+    HIP_TRY(hipEventCreate(&h->ev_poll[0]));
+    HIP_TRY(hipEventCreate(&h->ev_poll[1]));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_poll), 2 * sizeof(int), hipHostMallocDefault));
+    h->h_poll[0] = h->h_poll[1] = 0;
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(h->final_T, I, sizeof(I));
+    std::memset(h->final_hessian, 0, sizeof(h->final_hessian));
+    for (int i = 0; i < 6; ++i) h->final_hessian[i * 6 + i] = 1.0;  // impl/lsq_registration_impl.hpp:62
+    if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
+    if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
+    if (const char* s = std::getenv("NGICP_LANES")) h->lanes_per_query = std::atoi(s);
+    if (const char* s = std::getenv("NGICP_MAX_BLOCKS")) h->max_blocks = std::max(1, std::min(65536, std::atoi(s)));
+    *out = h.release();
+    return NGICP_OK;
+  } catch (const HipError& e) {
+    g_create_error = std::string("HIP error in ") + e.what + ": " + hipGetErrorString(e.code);
+    (void)hipGetLastError();
+    return NGICP_ERR_HIP;
+  } catch (...) {
+    g_create_error = "unknown error";
+    return NGICP_ERR_ARG;
+  }
+}
+
+int ngicp_destroy(ngicp_t* h) {
+  if (!h) return NGICP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->src.clear();
+  h->tgt.clear();
+  h->src_covs.clear();
+  h->tgt_covs.clear();
+  if (h->h_poll) (void)hipHostFree(h->h_poll);
+  if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+  if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+  for (int i = 0; i < 2; ++i)
+    if (h->ev_poll[i]) (void)hipEventDestroy(h->ev_poll[i]);
+  hipStream_t s = h->stream;
+  delete h;
+  if (s) (void)hipStreamDestroy(s);
+  return NGICP_OK;
+}
+
+const char* ngicp_last_error(const ngicp_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ngicp_set_params(ngicp_t* h, int k, double max_corr_dist, int max_iter, double trans_eps, double rot_eps, int optimizer, int lm_max_iter, double lm_init_lambda_factor,
+                     int regularization, int num_threads) {
+  return guarded(h, [&] {
+    if (regularization < 0 || regularization > 4) throw ArgError{NGICP_ERR_ARG, "unknown regularization method"};
+    if (optimizer != 0 && optimizer != 1) throw ArgError{NGICP_ERR_ARG, "unknown optimizer"};
+    h->p.k = k;
+    h->p.max_corr_dist = max_corr_dist;
+    h->p.max_iter = max_iter;
+    h->p.trans_eps = trans_eps;
+    h->p.rot_eps = rot_eps;
+    h->p.optimizer = optimizer;
+    h->p.lm_max_iter = lm_max_iter;
+    h->p.lm_init_lambda_factor = lm_init_lambda_factor;
+    h->p.regularization = regularization;
+    h->p.num_threads = num_threads;
+  });
+}
+
+int ngicp_set_tuning(ngicp_t* h, double voxel_size, int lanes_per_query) {
+  return guarded(h, [&] {
+    if (voxel_size < 0) throw ArgError{NGICP_ERR_ARG, "voxel_size must be >= 0"};
+    if (lanes_per_query != 0 && lanes_per_query != 1 && lanes_per_query != 2 && lanes_per_query != 4 && lanes_per_query != 8 && lanes_per_query != 16)
+      throw ArgError{NGICP_ERR_ARG, "lanes_per_query must be 0,1,2,4,8 or 16"};
+    h->voxel_size = voxel_size;
+    h->lanes_per_query = lanes_per_query;
+  });
+}
+
+int ngicp_set_source(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, uint64_t id) {
+  if (!h) return NGICP_ERR_ARG;
+  const bool same = (id != 0 && h->src.present && h->src.identity == id);
+  int rc = set_cloud(h, h->src, xyz, n, stride_bytes, id, true);
+  if (rc == NGICP_OK && !same) h->src_covs.clear();  // impl/nano_gicp_impl.hpp:128
+  return rc;
+}
+int ngicp_register_source(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, uint64_t id) {
+  if (!h) return NGICP_ERR_ARG;
+  return set_cloud(h, h->src, xyz, n, stride_bytes, id, false);  // covariances untouched (impl/nano_gicp_impl.hpp:113-118)
+}
+int ngicp_set_target(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, uint64_t id) {
+  if (!h) return NGICP_ERR_ARG;
+  const bool same = (id != 0 && h->tgt.present && h->tgt.identity == id);
+  int rc = set_cloud(h, h->tgt, xyz, n, stride_bytes, id, true);
+  if (rc == NGICP_OK && !same) h->tgt_covs.clear();  // :138
+  return rc;
+}
+int ngicp_clear_source(ngicp_t* h) {
+  return guarded(h, [&] {
+    h->src.clear();
+    h->src_covs.clear();
+  });
+}
+int ngicp_clear_target(ngicp_t* h) {
+  return guarded(h, [&] {
+    h->tgt.clear();
+    h->tgt_covs.clear();
+  });
+}
+
+int ngicp_share_source_index(ngicp_t* dst, ngicp_t* src) {
+  if (!src) return NGICP_ERR_ARG;
+  return guarded(dst, [&] {
+    if (dst->device != src->device) return;  // different GPUs: dst uploads its own copy lazily
+    if (!src->src.present || !src->src.dev) return;
+    if (!dst->src.present) return;
+    // adopt only when both refer to the same host cloud (the reference would otherwise rebuild the
+    // tree for its own cloud at impl/nano_gicp_impl.hpp:304-306)
+    const bool same = (dst->src.identity != 0 && dst->src.identity == src->src.identity) || (dst->src.host == src->src.host && dst->src.n == src->src.n);
+    if (same) {
+      HIP_TRY(hipStreamSynchronize(src->stream));
+      dst->src.dev = src->src.dev;
+    }
+  });
+}
+
+int ngicp_swap_source_target(ngicp_t* h) {
+  return guarded(h, [&] {
+    std::swap(h->src, h->tgt);
+    std::swap(h->src_covs, h->tgt_covs);
+    h->hook_valid = 0;  // correspondences_.clear(); sq_distances_.clear();
+  });
+}
+
+int ngicp_compute_source_covs(ngicp_t* h) {
+  return guarded(h, [&] { compute_covs(h, h->src, h->src_covs, "source"); });
+}
+int ngicp_compute_target_covs(ngicp_t* h) {
+  return guarded(h, [&] { compute_covs(h, h->tgt, h->tgt_covs, "target"); });
+}
+
+int ngicp_copy_source_covs(ngicp_t* dst, ngicp_t* src) {
+  if (!src) return NGICP_ERR_ARG;
+  return guarded(dst, [&] {
+    if (src->src_covs.n == 0) {
+      dst->src_covs.clear();
+      return;
+    }
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    if (dst->device == src->device) {
+      dst->src_covs = src->src_covs;  // shares the immutable device buffer
+    } else {
+      throw ArgError{NGICP_ERR_ARG, "copy_source_covs across devices is not supported; use get/set"};
+    }
+  });
+}
+int ngicp_clear_source_covs(ngicp_t* h) {
+  return guarded(h, [&] { h->src_covs.clear(); });
+}
+int ngicp_clear_target_covs(ngicp_t* h) {
+  return guarded(h, [&] { h->tgt_covs.clear(); });
+}
+int ngicp_source_covs_size(const ngicp_t* h, size_t* n) {
+  if (!h || !n) return NGICP_ERR_ARG;
+  *n = h->src_covs.n;
+  return NGICP_OK;
+}
+int ngicp_target_covs_size(const ngicp_t* h, size_t* n) {
+  if (!h || !n) return NGICP_ERR_ARG;
+  *n = h->tgt_covs.n;
+  return NGICP_OK;
+}
+int ngicp_get_source_covs(ngicp_t* h, double* out) {
+  return guarded(h, [&] {
+    if (!out) throw ArgError{NGICP_ERR_ARG, "null output"};
+    get_covs(h, h->src_covs, out);
+  });
+}
+int ngicp_get_target_covs(ngicp_t* h, double* out) {
+  return guarded(h, [&] {
+    if (!out) throw ArgError{NGICP_ERR_ARG, "null output"};
+    get_covs(h, h->tgt_covs, out);
+  });
+}
+int ngicp_set_source_covs(ngicp_t* h, const double* in, size_t n) {
+  return guarded(h, [&] { set_covs(h, h->src, h->src_covs, in, n, "source"); });
+}
+int ngicp_set_target_covs(ngicp_t* h, const double* in, size_t n) {
+  return guarded(h, [&] { set_covs(h, h->tgt, h->tgt_covs, in, n, "target"); });
+}
+
+int ngicp_align(ngicp_t* h, const float guess[16], float T_out[16], int* converged, int* nr_iterations, double final_hessian[36], float* aligned, size_t out_stride_bytes) {
+  int rc = guarded(h, [&] {
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (aligned && (out_stride_bytes < 12 || out_stride_bytes % 4)) throw ArgError{NGICP_ERR_ARG, "bad out_stride_bytes"};
+    do_align(h, guess ? guess : I, aligned, out_stride_bytes);
+  });
+  if (h) {
+    if (T_out) std::memcpy(T_out, h->final_T, sizeof(h->final_T));
+    if (converged) *converged = h->converged;
+    if (nr_iterations) *nr_iterations = h->nr_iterations;
+    if (final_hessian) std::memcpy(final_hessian, h->final_hessian, sizeof(h->final_hessian));
+  }
+  return rc;
+}
+
+int ngicp_linearize(ngicp_t* h, const double T[16], double H[36], double b[6], double* err) {
+  return guarded(h, [&] {
+    if (!T) throw ArgError{NGICP_ERR_ARG, "null pose"};
+    LoopCtx c;
+    prepare_loop(h, c);
+    LmState st;
+    init_state_from_pose(st, pose_from_colmajor_d(T));
+    HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+      c.pa.mode = 2 | 4;
+    launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+    c.sa.mode = 1;
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
+    HIP_TRY(hipMemcpyAsync(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+    if (H)
+      for (int r = 0; r < 6; ++r)
+        for (int cc = 0; cc < 6; ++cc) H[cc * 6 + r] = st.hot.H[r * 6 + cc];
+    if (b) std::memcpy(b, st.hot.b, sizeof(st.hot.b));
+    if (err) *err = st.hot.y0;
+    h->hook_valid = 1;
+  });
+}
+
+int ngicp_compute_error(ngicp_t* h, const double T[16], double* err) {
+  return guarded(h, [&] {
+    if (!T) throw ArgError{NGICP_ERR_ARG, "null pose"};
+    if (!h->hook_valid) throw ArgError{NGICP_ERR_STATE, "compute_error needs a preceding linearize"};
+    LoopCtx c;
+    prepare_loop(h, c);
+    // keep cur / have_lin, replace the trial pose
+    LmState st;
+    HIP_TRY(hipMemcpy(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost));
+    const Pose x = pose_from_colmajor_d(T);
+    st.hot.xi = x;
+    for (int r = 0; r < 3; ++r) {
+      for (int cc = 0; cc < 3; ++cc) st.xi_f[r * 4 + cc] = (float)x.R[r * 3 + cc];
+      st.xi_f[r * 4 + 3] = (float)x.t[r];
+    }
+    HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+    c.pa.mode = 1 | 4;
+    launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+    c.sa.mode = 2;
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
+    LmState st2;
+    HIP_TRY(hipMemcpyAsync(&st2, h->state.p, sizeof(st2), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+    if (err) *err = st2.hot.y0;
+  });
+}
+
+int ngicp_get_correspondences(ngicp_t* h, int* corr_out, float* sqd_out) {
+  return guarded(h, [&] {
+    if (!corr_out) throw ArgError{NGICP_ERR_ARG, "null output"};
+    if (!h->hook_valid) throw ArgError{NGICP_ERR_STATE, "no correspondences: call ngicp_linearize first"};
+    LmState st;
+    HIP_TRY(hipMemcpy(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost));
+    const size_t n = h->src.dev->n;
+    h->knn_idx.ensure(n * sizeof(int));
+    h->knn_d2.ensure(n * sizeof(float));
+    LmState* dst = h->state.as<LmState>();
+    hipLaunchKernelGGL(k_corr_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->corr[st.hot.cur].as<int>(), h->src.dev->sorted.as<float4>(),
+                       h->tgt.dev->sorted.as<float4>(), (int)n, h->knn_idx.as<int>(), sqd_out ? h->knn_d2.as<float>() : nullptr, dst->xi_f);
+    HIP_TRY(hipMemcpyAsync(corr_out, h->knn_idx.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (sqd_out) HIP_TRY(hipMemcpyAsync(sqd_out, h->knn_d2.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+  });
+}
+
+int ngicp_target_knn(ngicp_t* h, const float* q, size_t nq, size_t stride, int k, int* idx, float* d2) {
+  return guarded(h, [&] {
+    if (!q || !idx || !d2) throw ArgError{NGICP_ERR_ARG, "null pointer"};
+    if (nq == 0) return;
+    if (stride < 12 || stride % 4) throw ArgError{NGICP_ERR_ARG, "bad stride"};
+    ensure_slot_ready(h, h->tgt, "target");
+    DeviceCloud& T = *h->tgt.dev;
+    if (k <= 0) throw ArgError{NGICP_ERR_ARG, "k must be positive"};
+    if (k > 32 || (size_t)k > T.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
+    std::vector<float> packed(nq * 4);
+    for (size_t i = 0; i < nq; ++i) {
+      const float* p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(q) + i * stride);
+      packed[i * 4 + 0] = p[0];
+      packed[i * 4 + 1] = p[1];
+      packed[i * 4 + 2] = p[2];
+      packed[i * 4 + 3] = 1.f;
+    }
+    h->queries.ensure(nq * sizeof(float4));
+    h->knn_idx.ensure(nq * k * sizeof(int));
+    h->knn_d2.ensure(nq * k * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->queries.p, packed.data(), nq * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+    const dim3 grid((unsigned)((nq + 127) / 128)), block(128);
+    if (k <= 10)
+      hipLaunchKernelGGL(k_knn_queries<10>, grid, block, 0, h->stream, T.sorted.as<float4>(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+                         h->knn_idx.as<int>(), h->knn_d2.as<float>());
+    else if (k <= 20)
+      hipLaunchKernelGGL(k_knn_queries<20>, grid, block, 0, h->stream, T.sorted.as<float4>(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+                         h->knn_idx.as<int>(), h->knn_d2.as<float>());
+    else
+      hipLaunchKernelGGL(k_knn_queries<32>, grid, block, 0, h->stream, T.sorted.as<float4>(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+                         h->knn_idx.as<int>(), h->knn_d2.as<float>());
+    HIP_TRY(hipMemcpyAsync(idx, h->knn_idx.p, nq * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(d2, h->knn_d2.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+  });
+}
+
+int ngicp_get_lm_trace(ngicp_t* h, double* rows, size_t max_rows, size_t* n_rows) {
+  return guarded(h, [&] {
+    const size_t n = h->trace_host.size() / kTraceCols;
+    if (n_rows) *n_rows = n;
+    if (rows) std::memcpy(rows, h->trace_host.data(), std::min(n, max_rows) * kTraceCols * sizeof(double));
+  });
+}
+
+int ngicp_get_stats(ngicp_t* h, ngicp_stats* out) {
+  if (!h || !out) return NGICP_ERR_ARG;
+  *out = h->stats;
+  return NGICP_OK;
+}
+int ngicp_set_profiling(ngicp_t* h, int on) {
+  if (!h) return NGICP_ERR_ARG;
+  h->profiling = on != 0;
+  return NGICP_OK;
+}
+
+// ---- point-sharded stepping ----
+int ngicp_sharded_begin(ngicp_t* h, const float guess[16]) {
+  return guarded(h, [&] {
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    LoopCtx c;
+    prepare_loop(h, c);
+    LmState st;
+    init_state_from_pose(st, pose_from_colmajor_f(guess ? guess : I));
+    if (h->p.max_iter <= 0) st.hot.done = 1;
+    HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    h->sharded_active = true;
+    h->hook_valid = 0;
+  });
+}
+
+int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* stream_or_null) {
+  return guarded(h, [&] {
+    if (!h->sharded_active) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
+    if (!sums32_dev) throw ArgError{NGICP_ERR_ARG, "null sums buffer"};
+    hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : h->stream;
+    LoopCtx c;
+    prepare_loop(h, c);
+    c.pa.mode = ((h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3) | 4;
+    launch_pass(h, c.pa, c.lanes, c.nblocks, s);
+    c.sa.mode = 3;  // reduce only
+    c.sa.sums_out = sums32_dev;
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
+    HIP_TRY(hipGetLastError());
+  });
+}
+
+int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* stream_or_null, int* done) {
+  return guarded(h, [&] {
+    if (!h->sharded_active) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
+    hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : h->stream;
+    LoopCtx c;
+    prepare_loop(h, c);
+    c.sa.mode = 0;
+    c.sa.partials = sums32_dev;  // one pre-reduced vector
+    c.sa.nblocks = 1;
+    c.sa.pitch = 1;
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
+    LmState* dst = h->state.as<LmState>();
+    HIP_TRY(hipMemcpyAsync(&h->h_poll[0], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    if (done) *done = h->h_poll[0];
+  });
+}
+
+int ngicp_sharded_finish(ngicp_t* h, float T_out[16], int* converged, int* nr_iterations, double final_hessian[36]) {
+  return guarded(h, [&] {
+    LmState st;
+    HIP_TRY(hipMemcpy(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost));
+    pose_to_colmajor_f(st.hot.x0, h->final_T);
+    h->converged = st.hot.converged;
+    h->nr_iterations = st.hot.nr_iterations;
+    for (int r = 0; r < 6; ++r)
+      for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.final_hessian[r * 6 + cc];
+    if (T_out) std::memcpy(T_out, h->final_T, sizeof(h->final_T));
+    if (converged) *converged = h->converged;
+    if (nr_iterations) *nr_iterations = h->nr_iterations;
+    if (final_hessian) std::memcpy(final_hessian, h->final_hessian, sizeof(h->final_hessian));
+    h->sharded_active = false;
+  });
+}
+
+}  // extern "C"

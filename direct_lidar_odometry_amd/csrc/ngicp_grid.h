@@ -1,0 +1,248 @@
+// Voxel-grid spatial index (the GPU replacement of the reference's serial kd-tree build,
+// /root/reference/include/nano_gicp/impl/nanoflann_impl.hpp:1199-1211,867-1012).
+//
+// Layout in HBM per indexed cloud:
+//   sorted[n]      float4  {x, y, z, bitcast(original index)}  points in cell-major order
+//   cell_start[c]  int     first sorted position of linear cell c (ncells + 1 entries)
+// Linear cell id = (cz * ny + cy) * nx + cx (x fastest), so the 3 x-neighbours of a 27-cell
+// probe are ONE contiguous run of `sorted`: a ring-1 probe is 9 contiguous runs.
+// Points outside the grid are clamped into the border cells; the search bounds below stay
+// valid because a clamped point is never closer than its border cell's inner face.
+//
+// The build is a deterministic counting sort: histogram (int atomics) -> exclusive scan ->
+// scatter (int atomics; order inside a cell arbitrary) -> rank-by-original-index inside each
+// cell.  The final order is therefore a pure function of the input (bitwise reproducible).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ngk {
+
+struct Grid {
+  float ox, oy, oz;  // origin (min corner)
+  float h, inv_h;    // voxel edge
+  int nx, ny, nz;
+  int ncells;
+  float slack;       // conservative shrink of face distances (float cell-assignment rounding)
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void cell_coords(const Grid& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+  cx = clampi((int)floorf((x - g.ox) * g.inv_h), 0, g.nx - 1);
+  cy = clampi((int)floorf((y - g.oy) * g.inv_h), 0, g.ny - 1);
+  cz = clampi((int)floorf((z - g.oz) * g.inv_h), 0, g.nz - 1);
+}
+
+__device__ __forceinline__ int cell_linear(const Grid& g, int cx, int cy, int cz) { return (cz * g.ny + cy) * g.nx + cx; }
+
+// Squared lower bound on the distance from q to any indexed point OUTSIDE the explored box of
+// Chebyshev radius r around q's cell (cx,cy,cz).  Faces that coincide with the grid border have
+// nothing behind them (border cells hold the clamped outliers) and are ignored -> +inf when the
+// explored box covers the whole grid.
+__device__ __forceinline__ float unexplored_bound_sq(const Grid& g, float qx, float qy, float qz, int cx, int cy, int cz, int r) {
+  float best = 3.0e38f;
+  const float h = g.h;
+  if (cx - r > 0) best = fminf(best, qx - (g.ox + (float)(cx - r) * h));
+  if (cx + r < g.nx - 1) best = fminf(best, (g.ox + (float)(cx + r + 1) * h) - qx);
+  if (cy - r > 0) best = fminf(best, qy - (g.oy + (float)(cy - r) * h));
+  if (cy + r < g.ny - 1) best = fminf(best, (g.oy + (float)(cy + r + 1) * h) - qy);
+  if (cz - r > 0) best = fminf(best, qz - (g.oz + (float)(cz - r) * h));
+  if (cz + r < g.nz - 1) best = fminf(best, (g.oz + (float)(cz + r + 1) * h) - qz);
+  if (best > 1.0e38f) return 3.4028234664e38f;  // everything explored: FLT_MAX ends the search even when nothing was found
+  best = fmaxf(best - g.slack, 0.0f);
+  return best * best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Build kernels
+// ---------------------------------------------------------------------------------------------
+
+// raw strided host layout (already copied to the device) -> float4 {x,y,z,index}; per-block bbox
+// partials bbox_part[block][6] = {min x,y,z, max x,y,z} (reduced on the host: no contended atomics).
+__global__ void __launch_bounds__(256) k_unpack_bbox(const unsigned char* __restrict__ raw, size_t stride_bytes, int n, float4* __restrict__ pts,
+                                                      float* __restrict__ bbox_part) {
+  __shared__ float lds[4][6];
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float* p = reinterpret_cast<const float*>(raw + (size_t)i * stride_bytes);
+    float x = p[0], y = p[1], z = p[2];
+    pts[i] = make_float4(x, y, z, __int_as_float(i));
+    mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+    mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+    mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lds[wave][d] = mn[d];
+      lds[wave][3 + d] = mx[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    float v = lds[0][d];
+    for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, lds[w][d]) : fmaxf(v, lds[w][d]);
+    bbox_part[blockIdx.x * 6 + d] = v;
+  }
+}
+
+// histogram of points per cell; keys[i] = linear cell of point i
+__global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ pts, int n, Grid g, int* __restrict__ keys, int* __restrict__ counts) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    int cx, cy, cz;
+    cell_coords(g, p.x, p.y, p.z, cx, cy, cz);
+    int c = cell_linear(g, cx, cy, cz);
+    keys[i] = c;
+    atomicAdd(&counts[c], 1);
+  }
+}
+
+// Exclusive scan over `n` ints, 3 kernels, 4096 elements per block.
+// Also accumulates the occupancy statistic sum(count^2) through per-tile partials (no atomics).
+constexpr int kScanBlock = 256;
+constexpr int kScanPerThread = 16;
+constexpr int kScanTile = kScanBlock * kScanPerThread;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds /*>= 4 + 1 ints*/, int& block_total) {
+  // inclusive wave scan
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int wave_off = 0;
+  int total = 0;
+#pragma unroll
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    int s = lds[w];
+    if (w < wave) wave_off += s;
+    total += s;
+  }
+  __syncthreads();
+  block_total = total;
+  return wave_off + inc - v;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_tiles(const int* __restrict__ counts, int n, int* __restrict__ tile_sums,
+                                                           unsigned long long* __restrict__ tile_sq /*[ntiles] sum of count^2, or null*/) {
+  __shared__ int lds[8];
+  __shared__ unsigned long long lsq[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  int s = 0;
+  unsigned long long sq = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    int i = base + j;
+    int c = (i < n) ? counts[i] : 0;
+    s += c;
+    sq += (unsigned long long)c * (unsigned long long)c;
+  }
+  int total;
+  block_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+  if (tile_sq) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) lsq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sq[blockIdx.x] = lsq[0] + lsq[1] + lsq[2] + lsq[3];
+  }
+}
+
+// single block: exclusive scan of tile_sums in place (ntiles <= 1024 * per)
+__global__ void __launch_bounds__(kScanBlock) k_scan_tile_sums(int* __restrict__ tile_sums, int ntiles, const unsigned long long* __restrict__ tile_sq,
+                                                               unsigned long long* __restrict__ occ_out /*[1] sum of count^2*/) {
+  __shared__ int lds[8];
+  __shared__ int carry_s;
+  __shared__ unsigned long long lsq[4];
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  unsigned long long sq = 0;
+  for (int base = 0; base < ntiles; base += kScanBlock) {
+    int i = base + threadIdx.x;
+    int v = (i < ntiles) ? tile_sums[i] : 0;
+    if (tile_sq && i < ntiles) sq += tile_sq[i];
+    int total;
+    int ex = block_exclusive_scan(v, lds, total);
+    int carry = carry_s;
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (tile_sq) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0) lsq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) occ_out[0] = lsq[0] + lsq[1] + lsq[2] + lsq[3];
+  }
+}
+
+// out[i] = exclusive prefix of counts (out has n + 1 entries; out[n] = total)
+__global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int* __restrict__ counts, int n, const int* __restrict__ tile_offsets, int* __restrict__ out) {
+  __shared__ int lds[8];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  int c[kScanPerThread];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    int i = base + j;
+    c[j] = (i < n) ? counts[i] : 0;
+    s += c[j];
+  }
+  int total;
+  int ex = block_exclusive_scan(s, lds, total) + tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    int i = base + j;
+    if (i < n) out[i] = ex;
+    ex += c[j];
+    if (i == n - 1) out[n] = ex;
+  }
+}
+
+// scatter into cell segments (arbitrary order inside a cell)
+__global__ void __launch_bounds__(256) k_cell_scatter(const float4* __restrict__ pts, const int* __restrict__ keys, int n, const int* __restrict__ cell_start,
+                                                       int* __restrict__ fill, float4* __restrict__ tmp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int c = keys[i];
+    int pos = cell_start[c] + atomicAdd(&fill[c], 1);
+    tmp[pos] = pts[i];
+  }
+}
+
+// make the order inside each cell deterministic: rank by original index
+__global__ void __launch_bounds__(256) k_cell_rank(const float4* __restrict__ tmp, int n, Grid g, const int* __restrict__ cell_start, float4* __restrict__ sorted,
+                                                    int* __restrict__ perm) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    float4 me = tmp[p];
+    int cx, cy, cz;
+    cell_coords(g, me.x, me.y, me.z, cx, cy, cz);
+    int c = cell_linear(g, cx, cy, cz);
+    int s = cell_start[c], e = cell_start[c + 1];
+    int my = __float_as_int(me.w);
+    int rank = 0;
+    for (int q = s; q < e; ++q) rank += (__float_as_int(tmp[q].w) < my);
+    sorted[s + rank] = me;
+    perm[s + rank] = my;
+  }
+}
+
+}  // namespace ngk

@@ -1,0 +1,251 @@
+// Exact k-nearest-neighbour search on the voxel grid + per-point covariance estimation.
+// Replaces KdTreeFLANN::nearestKSearch (/root/reference/include/nano_gicp/nanoflann.hpp:141-152,
+// impl/nanoflann_impl.hpp:1230-1250,1355-1418) and NanoGICP::calculate_covariances
+// (impl/nano_gicp_impl.hpp:300-357).
+//
+// Exactness: rings of cells around the query cell are scanned until the k-th best squared
+// distance is <= the squared distance to the nearest unexplored cell face (eps = 0, like the
+// reference).  Distances are float32 ((dx*dx + dy*dy) + dz*dz, no FMA: this TU is compiled with
+// -ffp-contract=off) exactly as impl/nanoflann_impl.hpp:441-449.  Ties are broken by visiting
+// order with strict '<' like KNNResultSet::addPoint (impl/nanoflann_impl.hpp:184-211); the visiting
+// order differs from a kd-tree's, so among EXACTLY equal distances a different index may win
+// (SURVEY.md §7 "Ties").
+#pragma once
+#include "ngicp_grid.h"
+#include "ngicp_math.h"
+
+namespace ngk {
+
+// Sorted (ascending) top-K list in registers; all indices compile-time after unrolling.
+template <int K>
+struct TopK {
+  float d[K];
+  int id[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      d[s] = 3.4028234664e38f;  // FLT_MAX, KNNResultSet::init (impl/nanoflann_impl.hpp:168-174)
+      id[s] = -1;
+    }
+  }
+  // insert (dist, index) given dist < d[kth]; elements equal to dist stay in front (strict '>')
+  __device__ __forceinline__ void insert(float dist, int index) {
+#pragma unroll
+    for (int s = K - 1; s >= 1; --s) {
+      const bool shift = d[s - 1] > dist;
+      const bool here = !shift && (d[s] > dist);
+      const float nd = shift ? d[s - 1] : (here ? dist : d[s]);
+      const int ni = shift ? id[s - 1] : (here ? index : id[s]);
+      d[s] = nd;
+      id[s] = ni;
+    }
+    if (d[0] > dist) {
+      d[0] = dist;
+      id[0] = index;
+    }
+  }
+  __device__ __forceinline__ float kth(int k) const {
+    float v = d[0];
+#pragma unroll
+    for (int s = 1; s < K; ++s) v = (s == k - 1) ? d[s] : v;
+    return v;
+  }
+};
+
+__device__ __forceinline__ float sqdist(float qx, float qy, float qz, const float4& p) {
+  const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+  float r = dx * dx;
+  r = r + dy * dy;
+  r = r + dz * dz;
+  return r;
+}
+
+// scan one contiguous run of sorted points
+template <int K>
+__device__ __forceinline__ void scan_run(const float4* __restrict__ sorted, int s, int e, float qx, float qy, float qz, int k, TopK<K>& top, float& worst) {
+  for (int p = s; p < e; ++p) {
+    const float4 c = sorted[p];
+    const float d = sqdist(qx, qy, qz, c);
+    if (d < worst) {
+      top.insert(d, p);
+      worst = top.kth(k);
+    }
+  }
+}
+
+// Exact kNN of (qx,qy,qz) in an indexed cloud.  Result: top.id = SORTED positions, top.d ascending.
+template <int K>
+__device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                           int k, TopK<K>& top) {
+  top.init();
+  float worst = 3.4028234664e38f;
+  int cx, cy, cz;
+  cell_coords(g, qx, qy, qz, cx, cy, cz);
+  const int rmax = max(max(g.nx, g.ny), g.nz);
+  for (int r = 0; r <= rmax; ++r) {
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
+    const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
+    for (int z = z0; z <= z1; ++z) {
+      const bool zface = (z == cz - r) || (z == cz + r);
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * g.ny + y) * g.nx;
+        if (zface || y == cy - r || y == cy + r) {
+          scan_run<K>(sorted, cell_start[row + xa], cell_start[row + xb + 1], qx, qy, qz, k, top, worst);
+        } else {
+          if (cx - r >= 0) scan_run<K>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, k, top, worst);
+          if (cx + r <= g.nx - 1 && r > 0) scan_run<K>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, k, top, worst);
+        }
+      }
+    }
+    if (worst <= unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r)) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: covariance of every point of an indexed cloud (thread per point, sorted order)
+// covs6[i] = {xx,xy,xz,yy,yz,zz} of the regularised 3x3 (FP64), i = sorted position.
+// ---------------------------------------------------------------------------------------------
+enum { REG_NONE = 0, REG_MIN_EIG = 1, REG_NORMALIZED_MIN_EIG = 2, REG_PLANE = 3, REG_FROBENIUS = 4 };
+
+template <int K>
+__global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int n, int k, int reg,
+                                                      double* __restrict__ covs6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 q = sorted[i];
+  TopK<K> top;
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
+
+  // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k
+  double mx = 0, my = 0, mz = 0;
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+    if (s < k) {
+      const float4 p = sorted[top.id[s]];
+      mx += (double)p.x;
+      my += (double)p.y;
+      mz += (double)p.z;
+    }
+  const double inv_k = 1.0 / (double)k;
+  mx = mx / (double)k;
+  my = my / (double)k;
+  mz = mz / (double)k;
+  double C[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+    if (s < k) {
+      const float4 p = sorted[top.id[s]];
+      const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
+      C[0] += x * x; C[1] += x * y; C[2] += x * z;
+      C[3] += y * y; C[4] += y * z; C[5] += z * z;
+    }
+  (void)inv_k;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) C[e] = C[e] / (double)k;
+
+  double out[6];
+  if (reg == REG_NONE) {  // :323-324
+#pragma unroll
+    for (int e = 0; e < 6; ++e) out[e] = C[e];
+  } else if (reg == REG_FROBENIUS) {  // :325-330
+    double Cl[6] = {C[0] + 1e-3, C[1], C[2], C[3] + 1e-3, C[4], C[5] + 1e-3};
+    double Ci[6];
+    inv3_sym(Cl, Ci);
+    double nrm = Ci[0] * Ci[0] + Ci[3] * Ci[3] + Ci[5] * Ci[5] + 2.0 * (Ci[1] * Ci[1] + Ci[2] * Ci[2] + Ci[4] * Ci[4]);
+    nrm = sqrt(nrm);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) Ci[e] = Ci[e] / nrm;
+    inv3_sym(Ci, out);
+  } else {  // :331-353  SVD path (PLANE is the only mode DLO exercises)
+    double w[3], V[9];
+    eig3_sym(C, w, V);
+    const double a0 = fabs(w[0]), a1 = fabs(w[1]), a2 = fabs(w[2]);
+    double v0, v1, v2;
+    if (reg == REG_PLANE) {
+      // singular values sorted descending get (1, 1, 1e-3): the smallest one gets 1e-3
+      const int imin = (a0 <= a1 && a0 <= a2) ? 0 : ((a1 <= a2) ? 1 : 2);
+      v0 = imin == 0 ? 1e-3 : 1.0;
+      v1 = imin == 1 ? 1e-3 : 1.0;
+      v2 = imin == 2 ? 1e-3 : 1.0;
+    } else if (reg == REG_MIN_EIG) {
+      v0 = fmax(a0, 1e-3); v1 = fmax(a1, 1e-3); v2 = fmax(a2, 1e-3);
+    } else {
+      const double m = fmax(a0, fmax(a1, a2));
+      v0 = fmax(a0 / m, 1e-3); v1 = fmax(a1 / m, 1e-3); v2 = fmax(a2 / m, 1e-3);
+    }
+    // U diag(v) V^T with U == V (columns of V are eigenvectors)
+    out[0] = V[0] * v0 * V[0] + V[1] * v1 * V[1] + V[2] * v2 * V[2];
+    out[1] = V[0] * v0 * V[3] + V[1] * v1 * V[4] + V[2] * v2 * V[5];
+    out[2] = V[0] * v0 * V[6] + V[1] * v1 * V[7] + V[2] * v2 * V[8];
+    out[3] = V[3] * v0 * V[3] + V[4] * v1 * V[4] + V[5] * v2 * V[5];
+    out[4] = V[3] * v0 * V[6] + V[4] * v1 * V[7] + V[5] * v2 * V[8];
+    out[5] = V[6] * v0 * V[6] + V[7] * v1 * V[7] + V[8] * v2 * V[8];
+  }
+  double* o = covs6 + (size_t)i * 6;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) o[e] = out[e];
+}
+
+// Test hook: exact kNN of arbitrary queries (float4 xyz_) in an indexed cloud; outputs ORIGINAL indices.
+template <int K>
+__global__ void __launch_bounds__(128) k_knn_queries(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, const float4* __restrict__ queries,
+                                                      int nq, int k, int* __restrict__ out_idx, float* __restrict__ out_d2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const float4 q = queries[i];
+  TopK<K> top;
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+    if (s < k) {
+      const int pos = top.id[s];
+      out_idx[(size_t)i * k + s] = pos >= 0 ? __float_as_int(sorted[pos].w) : -1;
+      out_d2[(size_t)i * k + s] = pos >= 0 ? top.d[s] : __builtin_inff();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Covariance layout conversion at the API boundary (Eigen::Matrix4d image <-> packed symmetric)
+// ---------------------------------------------------------------------------------------------
+// packed sorted -> N x 16 column-major in ORIGINAL order
+__global__ void __launch_bounds__(256) k_covs_expand(const double* __restrict__ covs6, const int* __restrict__ perm, int n, double* __restrict__ out16) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* c = covs6 + (size_t)i * 6;
+  double* o = out16 + (size_t)perm[i] * 16;
+  o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = 0;
+  o[4] = c[1]; o[5] = c[3]; o[6] = c[4]; o[7] = 0;
+  o[8] = c[2]; o[9] = c[4]; o[10] = c[5]; o[11] = 0;
+  o[12] = 0; o[13] = 0; o[14] = 0; o[15] = 0;
+}
+// N x 16 column-major in ORIGINAL order -> packed sorted (upper triangle as stored: (r<=c) entries)
+__global__ void __launch_bounds__(256) k_covs_pack(const double* __restrict__ in16, const int* __restrict__ perm, int n, double* __restrict__ covs6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* m = in16 + (size_t)perm[i] * 16;
+  double* c = covs6 + (size_t)i * 6;
+  // column-major: m[col*4+row]
+  c[0] = m[0];   // (0,0)
+  c[1] = m[4];   // (0,1)
+  c[2] = m[8];   // (0,2)
+  c[3] = m[5];   // (1,1)
+  c[4] = m[9];   // (1,2)
+  c[5] = m[10];  // (2,2)
+}
+// reorder packed covs between two sorted orders of the same cloud: dst[i] = src[inv_src[perm_dst[i]]]
+__global__ void __launch_bounds__(256) k_invert_perm(const int* __restrict__ perm, int n, int* __restrict__ inv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inv[perm[i]] = i;
+}
+__global__ void __launch_bounds__(256) k_covs_reorder(const double* __restrict__ src6, const int* __restrict__ inv_src, const int* __restrict__ perm_dst, int n,
+                                                       double* __restrict__ dst6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* s = src6 + (size_t)inv_src[perm_dst[i]] * 6;
+  double* d = dst6 + (size_t)i * 6;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) d[e] = s[e];
+}
+
+}  // namespace ngk

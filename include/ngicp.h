@@ -1,0 +1,174 @@
+/* =============================================================================
+ * ngicp.h — C ABI of the MI355X-native NanoGICP scan-matching engine.
+ *
+ * One opaque handle per nano_gicp::NanoGICP<PointXYZI,PointXYZI> instance
+ * (DLO holds two: include/dlo/odom.h:119-120).  Plain pointers and sizes only:
+ * no C++/torch/PCL/Eigen types cross this boundary.  Paths below are relative to
+ * the reference tree (/root/reference/).
+ *
+ * Conventions
+ *  - every entry returns an int status: 0 = OK, <0 = error (ngicp_last_error()
+ *    gives the text); nothing throws or aborts across the boundary;
+ *  - a handle is single-caller at a time but may be called from any host thread
+ *    (DLO's AsyncSpinner(0): src/dlo/odom_node.cc:27); each entry selects the
+ *    handle's device and works on the handle's own HIP stream;
+ *  - clouds are given as a pointer to the first float of the first point plus a
+ *    byte stride (32 for pcl::PointXYZI, include/dlo/dlo.h:50; 12 for packed xyz);
+ *    only x,y,z are read.  `host_identity` is the caller's stand-in for the
+ *    reference's shared_ptr identity test (include/nano_gicp/impl/nano_gicp_impl.hpp:
+ *    114,122,133): a call with the identity already set on that slot is a no-op;
+ *    0 means "no identity, always re-upload";
+ *  - 4x4 matrices are column-major (Eigen default); covariances travel as the
+ *    reference's std::vector<Eigen::Matrix4d> memory image: N x 16 doubles,
+ *    column-major, 3x3 block + zero 4th row/column, in the cloud's ORIGINAL point
+ *    order (the engine keeps its own cell-sorted order internally).
+ * ============================================================================= */
+#ifndef NGICP_H
+#define NGICP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ngicp ngicp_t;
+
+/* status codes */
+#define NGICP_OK 0
+#define NGICP_ERR_HIP (-1)        /* a HIP runtime call failed (no device, OOM, ...) */
+#define NGICP_ERR_ARG (-2)        /* bad argument */
+#define NGICP_ERR_STATE (-3)      /* call sequence error (e.g. align() without target) */
+#define NGICP_ERR_K_TOO_LARGE (-4)/* k > cloud size or k > 32: undefined in the reference, explicit error here */
+
+/* regularisation (include/nano_gicp/gicp/gicp_settings.hpp:47) */
+#define NGICP_REG_NONE 0
+#define NGICP_REG_MIN_EIG 1
+#define NGICP_REG_NORMALIZED_MIN_EIG 2
+#define NGICP_REG_PLANE 3
+#define NGICP_REG_FROBENIUS 4
+
+/* optimiser (include/nano_gicp/lsq_registration.hpp:54) */
+#define NGICP_OPT_GAUSS_NEWTON 0
+#define NGICP_OPT_LEVENBERG_MARQUARDT 1
+
+/* --- lifetime ------------------------------------------------------------- */
+/* NanoGICP::NanoGICP()  impl/nano_gicp_impl.hpp:50-64 (+ LsqRegistration ctor
+ * impl/lsq_registration_impl.hpp:50-63): k=20, PLANE, LM, max_iter 64, rot_eps 2e-3,
+ * trans_eps 5e-4, lm_max 10, lambda factor 1e-9, corr dist FLT_MAX. */
+int ngicp_create(int device, ngicp_t** out);
+int ngicp_destroy(ngicp_t* h);
+const char* ngicp_last_error(const ngicp_t* h); /* h may be NULL: last create() error */
+const char* ngicp_version(void);
+
+/* --- parameters ----------------------------------------------------------- */
+/* setCorrespondenceRandomness impl/nano_gicp_impl.hpp:81-83; setMaxCorrespondenceDistance /
+ * setMaximumIterations / setTransformationEpsilon (PCL base; consumed at impl/nano_gicp_impl.hpp:195,
+ * impl/lsq_registration_impl.hpp:101,124); setRotationEpsilon / setInitialLambdaFactor
+ * impl/lsq_registration_impl.hpp:69-76; setRegularizationMethod impl/nano_gicp_impl.hpp:86-88;
+ * setNumThreads impl/nano_gicp_impl.hpp:70-78 (accepted, meaningless on the GPU). */
+int ngicp_set_params(ngicp_t* h, int k, double max_corr_dist, int max_iter, double trans_eps, double rot_eps,
+                     int optimizer, int lm_max_iter, double lm_init_lambda_factor, int regularization, int num_threads);
+/* engine knobs with no reference counterpart: voxel edge of the search grid in metres
+ * (0 = automatic) and lanes cooperating on one query in the per-iteration kernel (0 = automatic). */
+int ngicp_set_tuning(ngicp_t* h, double voxel_size, int lanes_per_query);
+
+/* --- clouds --------------------------------------------------------------- */
+/* setInputSource impl/nano_gicp_impl.hpp:121-129: store cloud, (re)build index, clear source covs. */
+int ngicp_set_source(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, uint64_t host_identity);
+/* registerInputSource impl/nano_gicp_impl.hpp:113-118: store cloud only; covariances untouched.
+ * The pointer must stay valid until the next set/register/clear of the source (the reference
+ * holds a shared_ptr): upload is deferred so that ngicp_share_source_index can avoid it. */
+int ngicp_register_source(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, uint64_t host_identity);
+/* setInputTarget impl/nano_gicp_impl.hpp:132-139 */
+int ngicp_set_target(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, uint64_t host_identity);
+/* clearSource / clearTarget impl/nano_gicp_impl.hpp:101-110 */
+int ngicp_clear_source(ngicp_t* h);
+int ngicp_clear_target(ngicp_t* h);
+/* `gicp.source_kdtree_ = gicp_s2s.source_kdtree_;`  src/dlo/odom.cc:525 — dst adopts src's
+ * device-resident source cloud + index when it refers to the same host cloud. */
+int ngicp_share_source_index(ngicp_t* dst, ngicp_t* src);
+/* swapSourceAndTarget impl/nano_gicp_impl.hpp:91-98 */
+int ngicp_swap_source_target(ngicp_t* h);
+
+/* --- covariances ---------------------------------------------------------- */
+/* calculateSourceCovariances / calculateTargetCovariances impl/nano_gicp_impl.hpp:152-159,300-357 */
+int ngicp_compute_source_covs(ngicp_t* h);
+int ngicp_compute_target_covs(ngicp_t* h);
+/* `gicp.source_covs_ = gicp_s2s.source_covs_;` src/dlo/odom.cc:815 (device-to-device) */
+int ngicp_copy_source_covs(ngicp_t* dst, ngicp_t* src);
+/* `gicp.source_covs_.clear();` src/dlo/odom.cc:526 */
+int ngicp_clear_source_covs(ngicp_t* h);
+int ngicp_clear_target_covs(ngicp_t* h);
+/* source_covs_.size() / target_covs_.size() */
+int ngicp_source_covs_size(const ngicp_t* h, size_t* n);
+int ngicp_target_covs_size(const ngicp_t* h, size_t* n);
+/* getSourceCovariances / getTargetCovariances include/nano_gicp/nano_gicp.hpp:100-106 */
+int ngicp_get_source_covs(ngicp_t* h, double* out_n16);
+int ngicp_get_target_covs(ngicp_t* h, double* out_n16);
+/* setSourceCovariances / setTargetCovariances impl/nano_gicp_impl.hpp:142-149 */
+int ngicp_set_source_covs(ngicp_t* h, const double* in_n16, size_t n);
+int ngicp_set_target_covs(ngicp_t* h, const double* in_n16, size_t n);
+
+/* --- registration --------------------------------------------------------- */
+/* pcl::Registration::align(output, guess) -> NanoGICP::computeTransformation
+ * impl/nano_gicp_impl.hpp:162-171 -> LsqRegistration::computeTransformation
+ * impl/lsq_registration_impl.hpp:89-115.  Outputs: final_transformation_ (float 4x4),
+ * converged_, nr_iterations_ (index of the last iteration), final_hessian_ (6x6), and — when
+ * aligned_xyz_or_null != NULL — the source cloud transformed by the float matrix
+ * (pcl::transformPointCloud, impl/lsq_registration_impl.hpp:114), xyz written at out_stride_bytes. */
+int ngicp_align(ngicp_t* h, const float guess_colmajor[16], float T_out_colmajor[16], int* converged, int* nr_iterations,
+                double final_hessian_colmajor[36], float* aligned_xyz_or_null, size_t out_stride_bytes);
+
+/* --- parity / test hooks --------------------------------------------------- */
+/* NanoGICP::linearize impl/nano_gicp_impl.hpp:214-270 (includes update_correspondences :174-211) */
+int ngicp_linearize(ngicp_t* h, const double T_colmajor[16], double H_colmajor[36], double b[6], double* err);
+/* NanoGICP::compute_error impl/nano_gicp_impl.hpp:273-296 (stale correspondences of the last linearize) */
+int ngicp_compute_error(ngicp_t* h, const double T_colmajor[16], double* err);
+/* correspondences_ / sq_distances_ of the last linearize, mapped back to ORIGINAL source/target
+ * point indices (-1 = gated out). sq_dist may be NULL. */
+int ngicp_get_correspondences(ngicp_t* h, int* corr_n, float* sq_dist_n_or_null);
+/* exact k-NN of arbitrary query points in the TARGET cloud (KdTreeFLANN::nearestKSearch,
+ * include/nano_gicp/nanoflann.hpp:141-152): original target indices + float squared distances, ascending. */
+int ngicp_target_knn(ngicp_t* h, const float* queries_xyz, size_t nq, size_t stride_bytes, int k, int* idx_nq_k, float* sqd_nq_k);
+/* LM trace of the last align(): rows of 8 doubles {outer, trial, y0, yi, rho, lambda, |d|, accepted}
+ * (the columns setDebugPrint prints, impl/lsq_registration_impl.hpp:183-189). */
+int ngicp_get_lm_trace(ngicp_t* h, double* rows8_or_null, size_t max_rows, size_t* n_rows);
+
+/* --- measurement ----------------------------------------------------------- */
+typedef struct ngicp_stats {
+  double align_ms;          /* host wall time of the last ngicp_align() */
+  double loop_ms;           /* device time (HIP events on the handle's stream) of the iteration loop */
+  double pass_ms_total;     /* device time summed over the per-iteration kernels of the last align */
+  int passes;               /* per-iteration kernels launched that did work (= linearisations incl. the speculative last one) */
+  int outer_iterations;     /* nr_iterations_ + 1 */
+  int lm_trials;            /* LM trials evaluated */
+  double mean_candidates;   /* C-bar: target points distance-tested per source point per pass */
+  double valid_fraction;    /* fraction of source points with a correspondence in the last pass */
+  double index_build_ms;    /* device time of the last index build on this handle */
+  double covariance_ms;     /* device time of the last covariance computation */
+  double upload_ms;         /* host wall time of the last cloud upload */
+  double voxel_size;        /* target grid voxel edge in use */
+  int grid_dims[3];
+  int lanes_per_query;
+} ngicp_stats;
+int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
+/* collect per-kernel HIP-event timing inside align (adds event overhead; off by default) */
+int ngicp_set_profiling(ngicp_t* h, int on);
+
+/* --- point-sharded multi-GPU stepping ------------------------ */
+/* One GICP pass over this handle's source block at the engine's current trial pose: writes 32 doubles
+ * {H upper-tri 21, b 6, y0, yi, candidates tested, valid correspondences, 0} to device memory
+ * `sums32_dev` (caller all-reduces them, e.g. RCCL via torch.distributed: 256 B, latency-bound), then
+ * ngicp_sharded_step consumes the reduced sums and advances the LM state machine identically on every
+ * rank.  *done is set when the alignment finished. */
+int ngicp_sharded_begin(ngicp_t* h, const float guess_colmajor[16]);
+int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* hip_stream_or_null);
+int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* hip_stream_or_null, int* done);
+int ngicp_sharded_finish(ngicp_t* h, float T_out_colmajor[16], int* converged, int* nr_iterations, double final_hessian_colmajor[36]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGICP_H */
