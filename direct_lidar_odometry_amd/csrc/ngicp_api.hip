@@ -236,18 +236,23 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
   h->keys.ensure(n * sizeof(int));
   h->tmp.ensure(n * sizeof(float4));
   const int bbox_blocks = pick_blocks(n, 1024, 512);
-  h->bbox.ensure((size_t)bbox_blocks * 6 * sizeof(float));
+  h->bbox.ensure((size_t)bbox_blocks * 8 * sizeof(float));
   h->occ.ensure(2 * sizeof(unsigned long long));
   hipLaunchKernelGGL(k_unpack_bbox, dim3(bbox_blocks), dim3(256), 0, h->stream, h->raw.as<unsigned char>(), stride, ni, h->unsorted.as<float4>(), h->bbox.as<float>());
-  std::vector<float> bb((size_t)bbox_blocks * 6);
+  std::vector<float> bb((size_t)bbox_blocks * 8);
   HIP_TRY(hipMemcpyAsync(bb.data(), h->bbox.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int b = 0; b < bbox_blocks; ++b)
+  float bad = 0.f;
+  for (int b = 0; b < bbox_blocks; ++b) {
     for (int d = 0; d < 3; ++d) {
-      mn[d] = std::min(mn[d], bb[(size_t)b * 6 + d]);
-      mx[d] = std::max(mx[d], bb[(size_t)b * 6 + 3 + d]);
+      mn[d] = std::min(mn[d], bb[(size_t)b * 8 + d]);
+      mx[d] = std::max(mx[d], bb[(size_t)b * 8 + 3 + d]);
     }
+    bad += bb[(size_t)b * 8 + 6];
+  }
+  // the reference assumes NaNs were removed upstream (src/dlo/odom.cc:443-447); make it an explicit error
+  if (bad > 0.f) throw ArgError{NGICP_ERR_ARG, "cloud contains non-finite coordinates"};
   for (int d = 0; d < 3; ++d)
     if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || mn[d] > mx[d]) throw ArgError{NGICP_ERR_ARG, "cloud contains non-finite coordinates"};
   const int max_cells = 1 << 25;
@@ -665,7 +670,14 @@ int set_cloud(ngicp* h, Slot& slot, const float* xyz, size_t n, size_t stride, u
     slot.n = n;
     slot.stride = stride;
     slot.identity = identity;
-    if (build_now) slot.dev = upload_and_index(h, xyz, n, stride);
+    if (build_now) {
+      try {
+        slot.dev = upload_and_index(h, xyz, n, stride);
+      } catch (...) {
+        slot.clear();  // a rejected cloud leaves the slot empty
+        throw;
+      }
+    }
   });
 }
 

@@ -59,15 +59,17 @@ __device__ __forceinline__ float unexplored_bound_sq(const Grid& g, float qx, fl
 // ---------------------------------------------------------------------------------------------
 
 // raw strided host layout (already copied to the device) -> float4 {x,y,z,index}; per-block bbox
-// partials bbox_part[block][6] = {min x,y,z, max x,y,z} (reduced on the host: no contended atomics).
+// partials bbox_part[block][8] = {min x,y,z, max x,y,z, #non-finite points, 0} (reduced on the host: no contended atomics).
 __global__ void __launch_bounds__(256) k_unpack_bbox(const unsigned char* __restrict__ raw, size_t stride_bytes, int n, float4* __restrict__ pts,
                                                       float* __restrict__ bbox_part) {
-  __shared__ float lds[4][6];
+  __shared__ float lds[4][7];
   float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  float bad = 0.f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float* p = reinterpret_cast<const float*>(raw + (size_t)i * stride_bytes);
     float x = p[0], y = p[1], z = p[2];
     pts[i] = make_float4(x, y, z, __int_as_float(i));
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) bad += 1.f;
     mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
     mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
     mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
@@ -80,6 +82,8 @@ __global__ void __launch_bounds__(256) k_unpack_bbox(const unsigned char* __rest
       mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
     }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
@@ -87,13 +91,14 @@ __global__ void __launch_bounds__(256) k_unpack_bbox(const unsigned char* __rest
       lds[wave][d] = mn[d];
       lds[wave][3 + d] = mx[d];
     }
+    lds[wave][6] = bad;
   }
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < 7) {
     const int d = threadIdx.x;
     float v = lds[0][d];
-    for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, lds[w][d]) : fmaxf(v, lds[w][d]);
-    bbox_part[blockIdx.x * 6 + d] = v;
+    for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, lds[w][d]) : (d < 6 ? fmaxf(v, lds[w][d]) : v + lds[w][d]);
+    bbox_part[blockIdx.x * 8 + d] = v;
   }
 }
 

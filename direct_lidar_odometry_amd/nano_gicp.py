@@ -79,6 +79,9 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; importing torch first makes
+    # this extension bind to that same runtime (loading /opt/rocm's copy first leaves torch without GPUs).
+    import torch  # noqa: F401  (plumbing: streams, device memory for collectives, torch.distributed)
     if not os.path.exists(_LIB_PATH):
         raise ImportError(f"{_LIB_PATH} not found: build it with `python -m direct_lidar_odometry_amd.build` "
                           "(or __graft_entry__.build()); this package has no CPU fallback")

@@ -1,0 +1,82 @@
+"""Multi-GPU host logic for the NanoGICP path.  One process per GPU; torch.distributed
+("nccl" == RCCL over xGMI on the GPU node, "gloo" in CPU tests) is plumbing only.
+
+Two ways the path shards:
+ 1. independent alignments (keyframes / scans): `partition_items` deals them to ranks, no data-path
+    collective; `gather_results` collects the 4x4 results for reporting.
+ 2. one large alignment, point-sharded: the SOURCE points are split into contiguous blocks
+    (`shard_bounds`), the target (+ covariances) is replicated, every rank runs the fused pass on its
+    block and the 32-double partial-sum vector {H upper-tri 21, b 6, y0, yi, candidates, valid, 0} is
+    summed with one all-reduce per pass (256 B: latency-bound; xGMI link bandwidth is irrelevant);
+    every rank then advances the identical LM state machine, so poses stay bit-identical without a
+    broadcast (`sharded_align`).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SUMS_LEN = 32  # include/ngicp.h: ngicp_sharded_pass
+
+
+def partition_items(n_items: int, world_size: int, rank: int) -> list[int]:
+    """Round-robin deal of independent alignments to ranks."""
+    return list(range(rank, n_items, world_size))
+
+
+def shard_bounds(n: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one point."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def tri21(r: int, c: int) -> int:
+    """Index of H(r,c), r <= c, in the packed upper triangle (csrc/ngicp_pass.h tri21)."""
+    return r * 6 - (r * (r - 1)) // 2 + (c - r)
+
+
+def pack_sums(H: np.ndarray, b: np.ndarray, y0: float, yi: float = 0.0, cand: float = 0.0, valid: float = 0.0) -> np.ndarray:
+    v = np.zeros(SUMS_LEN)
+    for r in range(6):
+        for c in range(r, 6):
+            v[tri21(r, c)] = H[r, c]
+    v[21:27] = b
+    v[27], v[28], v[29], v[30] = y0, yi, cand, valid
+    return v
+
+
+def unpack_sums(v: np.ndarray):
+    H = np.zeros((6, 6))
+    for r in range(6):
+        for c in range(r, 6):
+            H[r, c] = H[c, r] = v[tri21(r, c)]
+    return H, np.array(v[21:27]), float(v[27]), float(v[28])
+
+
+def gather_results(T_local: list[np.ndarray], dist, device=None):
+    """All ranks' 4x4 results -> list on every rank (reporting only; not on the data path)."""
+    import torch
+    t = torch.tensor(np.stack(T_local).astype(np.float32) if T_local else np.zeros((0, 4, 4), np.float32), device=device)
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(dist.get_world_size())]
+    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=device))
+    m = max(int(c.item()) for c in counts)
+    pad = torch.zeros((m, 4, 4), dtype=torch.float32, device=device)
+    pad[: t.shape[0]] = t
+    outs = [torch.zeros_like(pad) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, pad)
+    return [o[: int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]
+
+
+def sharded_align(engine, guess, dist, torch_device):
+    """Point-sharded alignment on the HIP engine.  `engine` already holds this rank's source block, the
+    full target and both covariance sets.  Returns the final 4x4 (identical on every rank)."""
+    import torch
+    sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=torch_device)
+    stream = torch.cuda.current_stream(torch_device).cuda_stream
+    engine.sharded_begin(guess)
+    while True:
+        engine.sharded_pass(sums.data_ptr(), stream)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        if engine.sharded_step(sums.data_ptr(), stream):
+            break
+    return engine.sharded_finish()

@@ -403,6 +403,7 @@ static void inv3_general(const double m[3][3], double o[3][3]) {
 // Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (stands in for
 // JacobiSVD<Matrix3d> at impl/nano_gicp_impl.hpp:332: for a symmetric PSD
 // matrix U == V == eigenvectors and the singular values are the eigenvalues).
+// Classical (Rutishauser) rotation update: a_pp -= t a_pq, a_qq += t a_pq.
 // Output: w descending, V columns are the matching unit eigenvectors.
 static void eig3_sym(const double a_in[3][3], double w[3], double V[3][3]) {
   double a[3][3];
@@ -411,37 +412,34 @@ static void eig3_sym(const double a_in[3][3], double w[3], double V[3][3]) {
       a[i][j] = a_in[i][j];
       V[i][j] = (i == j) ? 1.0 : 0.0;
     }
-  for (int sweep = 0; sweep < 32; ++sweep) {
+  static const int PQ[3][3] = {{0, 1, 2}, {0, 2, 1}, {1, 2, 0}};  // (p, q, r): pivot pair and the third index
+  for (int sweep = 0; sweep < 24; ++sweep) {
     double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
     double diag = std::fabs(a[0][0]) + std::fabs(a[1][1]) + std::fabs(a[2][2]);
     if (off <= 1e-300 || off <= 1e-22 * diag) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        double apq = a[p][q];
-        if (apq == 0.0) continue;
-        double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 3; ++k) {  // A <- A * G
-          double akp = a[k][p], akq = a[k][q];
-          a[k][p] = c * akp - s * akq;
-          a[k][q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < 3; ++k) {  // A <- G^T * A
-          double apk = a[p][k], aqk = a[q][k];
-          a[p][k] = c * apk - s * aqk;
-          a[q][k] = s * apk + c * aqk;
-        }
-        for (int k = 0; k < 3; ++k) {
-          double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq;
-          V[k][q] = s * vkp + c * vkq;
-        }
+    for (int e = 0; e < 3; ++e) {
+      const int p = PQ[e][0], q = PQ[e][1], r = PQ[e][2];
+      const double apq = a[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+      const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+      a[p][p] = a[p][p] - t * apq;
+      a[q][q] = a[q][q] + t * apq;
+      a[p][q] = a[q][p] = 0.0;
+      const double rp = a[r][p], rq = a[r][q];
+      a[r][p] = a[p][r] = c * rp - s * rq;
+      a[r][q] = a[q][r] = s * rp + c * rq;
+      for (int k = 0; k < 3; ++k) {
+        const double vp = V[k][p], vq = V[k][q];
+        V[k][p] = c * vp - s * vq;
+        V[k][q] = s * vp + c * vq;
       }
+    }
   }
   int order[3] = {0, 1, 2};
   double d[3] = {a[0][0], a[1][1], a[2][2]};
-  std::sort(order, order + 3, [&](int x, int y) { return d[x] > d[y]; });
+  std::sort(order, order + 3, [&](int x, int y) { return std::fabs(d[x]) > std::fabs(d[y]); });
   double Vs[3][3];
   for (int j = 0; j < 3; ++j) {
     w[j] = d[order[j]];
