@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py — GICP iterations/s + ms/scan of the NanoGICP align() hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): scan-to-submap,
+100k-point VLP-16-shaped source vs a 500k-point submap (5 keyframes x 100k, per-keyframe world-frame
+covariances supplied as DLO does), k = 20, max-corr 0.5 m, exactly 20 GICP iterations per align()
+(transformation/rotation epsilon 1e-12).  One "step" = one complete align() = 20 outer iterations
+(21 fused passes).  Clouds, indices and covariances are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): independent alignments, one workload per
+rank with seeds offset by 1000*rank (BASELINE config 4) — weak scaling, no data-path collective; the
+barrier + max-over-ranks timing below is the only communication.
+
+Prints ONE JSON line (rank 0): metric/value/unit + roofline (dominant kernel k_gicp_pass, HIP-event
+timed on the engine's own stream) + cpu_baseline (the CPU oracle, OpenMP, timed on this box's host
+cores, rank 0 at N == 1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GICP_ITERS = 20
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def build_workload(rank: int):
+    from direct_lidar_odometry_amd import clouds
+    return clouds.scan_to_submap(100_000, 5, seed_offset=1000 * rank)
+
+
+def keyframe_covariances(ng, w):
+    """Per-keyframe covariances in the world frame, concatenated (src/dlo/odom.cc:1172-1174,1318-1325)."""
+    e = ng.NanoGICP()
+    out, lo = [], 0
+    for n in w.keyframe_sizes:
+        e.setInputSource(np.ascontiguousarray(w.target[lo:lo + n]))
+        e.calculateSourceCovariances()
+        out.append(e.getSourceCovariances())
+        lo += n
+    e.close()
+    return np.concatenate(out)
+
+
+def cpu_baseline(w, tgt_covs, src_covs):
+    """CPU oracle (oracle/ = C++/OpenMP restatement of the reference path) on the same clouds: bounded sample."""
+    from oracle import oracle as orc
+    orc.build(ref=False)
+    o = orc.OracleGICP()
+    o.setNumThreads(0)  # omp_get_max_threads(), like the reference (impl/nano_gicp_impl.hpp:51-55)
+    threads = o.numThreads()
+    o.setMaxCorrespondenceDistance(w.max_corr_dist)
+    o.setTransformationEpsilon(1e-12); o.setRotationEpsilon(1e-12)
+    t0 = time.perf_counter()
+    o.setInputTarget(w.target)  # serial kd-tree build over 500k points
+    build_s = time.perf_counter() - t0
+    o.setInputSource(w.source)
+    o.setSourceCovariances(src_covs); o.setTargetCovariances(tgt_covs)
+    o.setMaximumIterations(2); o.align(w.guess)  # warm-up
+    o.setMaximumIterations(GICP_ITERS)
+    done, aligns, budget_s = 0, 0, 4.0
+    t0 = time.perf_counter()
+    while True:
+        o.align(w.guess)
+        done += o.nr_iterations + 1
+        aligns += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or aligns >= 200:
+            break
+    return {"value": done / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": f"{aligns} align() calls of the same 100k->500k workload ({done} outer GICP iterations, {dt:.1f} s wall = "
+                      f"{dt * threads:.0f} thread-seconds), OpenMP {threads} threads (host has {os.cpu_count()} cpus); "
+                      f"{dt * 1e3 / done:.2f} ms/iteration; serial kd-tree build of the 500k target ({build_s * 1e3:.0f} ms) not included",
+            "ms_per_iteration": dt * 1e3 / done, "ms_per_scan": dt * 1e3 / aligns, "target_index_build_ms": build_s * 1e3}, o.getFinalTransformation()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" == RCCL on ROCm
+
+    from direct_lidar_odometry_amd import build, clouds, nano_gicp as ng
+    build.build()
+
+    w = build_workload(rank)
+    tgt_covs = keyframe_covariances(ng, w)
+    g = ng.NanoGICP(device=local_rank)
+    g.setCorrespondenceRandomness(20)
+    g.setMaxCorrespondenceDistance(w.max_corr_dist)
+    g.setMaximumIterations(GICP_ITERS); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
+    t0 = time.perf_counter(); g.setInputTarget(w.target); t_target = time.perf_counter() - t0
+    st_t = g.stats()
+    g.setTargetCovariances(tgt_covs)
+    t0 = time.perf_counter(); g.setInputSource(w.source); t_source = time.perf_counter() - t0
+    st_s = g.stats()
+    g.calculateSourceCovariances()
+    st_c = g.stats()
+    src_covs = g.getSourceCovariances()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.align(w.guess)
+    g.setProfiling(True)
+    iters_done = 0
+    passes = 0
+    pass_ms = 0.0
+    cand = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.align(w.guess)  # returns after the final pose has been read back (stream-synchronous)
+        s = g.stats()
+        iters_done += s["outer_iterations"]
+        passes += s["passes_timed"]
+        pass_ms += s["pass_ms_total"]
+        cand += s["mean_candidates"] * s["passes"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        it = torch.tensor([float(iters_done)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        total_iters = float(it.item())
+    else:
+        total_iters = float(iters_done)
+    g.setProfiling(False)
+    T_gpu = g.getFinalTransformation().copy()
+
+    if rank == 0:
+        s = g.stats()
+        n_src = s["n_src"]
+        cbar = cand / max(1, args.steps * s["passes"])
+        avg_pass_ms = pass_ms / max(1, passes)
+        # bytes per iteration = N_s * (12*Cbar + 100 + 52*n_trials); the fused pass carries one
+        # trial's K4 reads except in the first pass of an align (no previous linearisation yet)
+        k4_frac = (s["passes"] - 1) / max(1, s["passes"])
+        bytes_per_launch = n_src * (12.0 * cbar + 100.0 + 52.0 * k4_frac)
+        achieved = bytes_per_launch / (avg_pass_ms * 1e-3) / 1e9 if avg_pass_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pass_hbm_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "gicp_iterations_per_sec",
+            "value": total_iters / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",  # FP64 normal equations / covariances / LM; float32 only for the NN query, as the reference
+            "data": "synthetic",
+            "config": {"workload": "scan_to_submap_100k_vs_500k (BASELINE configs[2]; configs[3] = one such align per GPU)",
+                       "source_points": int(n_src), "target_points": int(s["n_tgt"]), "k_correspondences": 20,
+                       "gicp_iterations_per_align": GICP_ITERS, "max_corr_dist_m": w.max_corr_dist,
+                       "optimizer": "LevenbergMarquardt", "parallelism": f"independent_aligns_x{world}"},
+            "ms_per_scan": elapsed * 1e3 / args.steps,
+            "iterations_per_align": iters_done / args.steps,
+            "setup_ms": {"set_target_upload_index": t_target * 1e3, "target_index_build_device": st_t["index_build_ms"],
+                         "set_source_upload_index": t_source * 1e3, "source_index_build_device": st_s["index_build_ms"],
+                         "source_covariances_device": st_c["covariance_ms"]},
+            "engine": {"voxel_m": s["voxel_size"], "grid": s["grid_dims"], "lanes_per_query": s["lanes_per_query"],
+                       "mean_candidates_per_query": cbar, "valid_fraction": s["valid_fraction"], "passes_per_align": s["passes"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_gicp_pass", "avg_launch_ms": avg_pass_ms, "launches_timed": passes,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "floor_frac_cbar1": (n_src * (12.0 + 100.0 + 52.0 * k4_frac) / (avg_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_pass_ms > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, T_cpu = cpu_baseline(w, tgt_covs, src_covs)
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,7 @@ struct ngicp {
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
+  std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
   int hook_valid = 0;     // linearize hook has produced correspondences
 
@@ -403,8 +404,7 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
 int auto_lanes(size_t n_src) {
   // fill the chip (256 CUs x 2048 threads): cooperate more when there are few queries
   if (n_src >= 1000000) return 2;
-  if (n_src >= 400000) return 4;
-  return 8;
+  return 4;
 }
 
 template <int G>
@@ -576,7 +576,10 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       }
     }
     for (int i = 0; i < chunk && launched < max_passes; ++i, ++launched) {
+      const bool timed = h->profiling && (size_t)(2 * launched + 1) < h->prof_events.size();
+      if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched], h->stream));
       launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+      if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched + 1], h->stream));
       hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     }
     HIP_TRY(hipMemcpyAsync(&h->h_poll[slot], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -630,7 +633,20 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   s.lm_trials = st.hot.n_trace;
   s.mean_candidates = st.hot.passes > 0 ? st.hot.cand_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
   s.valid_fraction = st.hot.passes > 0 ? st.hot.valid_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
-  s.pass_ms_total = loop_ms;
+  s.pass_ms_total = 0.0;
+  if (h->profiling) {
+    // HIP events on the handle's own stream around every pass launch that did work
+    const long timed = std::min<long>(st.hot.passes, (long)h->prof_events.size() / 2);
+    for (long i = 0; i < timed; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->prof_events[2 * i], h->prof_events[2 * i + 1]) == hipSuccess) s.pass_ms_total += ms;
+    }
+    s.passes_timed = (int)timed;
+  } else {
+    s.passes_timed = 0;
+  }
+  s.n_src = (long long)h->src.dev->n;
+  s.n_tgt = (long long)h->tgt.dev->n;
   s.align_ms = now_ms() - t_begin;
 }
 
@@ -741,6 +757,8 @@ int ngicp_destroy(ngicp_t* h) {
   h->tgt.clear();
   h->src_covs.clear();
   h->tgt_covs.clear();
+  for (auto& e : h->prof_events)
+    if (e) (void)hipEventDestroy(e);
   if (h->h_poll) (void)hipHostFree(h->h_poll);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -1032,9 +1050,13 @@ int ngicp_get_stats(ngicp_t* h, ngicp_stats* out) {
   return NGICP_OK;
 }
 int ngicp_set_profiling(ngicp_t* h, int on) {
-  if (!h) return NGICP_ERR_ARG;
-  h->profiling = on != 0;
-  return NGICP_OK;
+  return guarded(h, [&] {
+    h->profiling = on != 0;
+    if (h->profiling && h->prof_events.empty()) {
+      h->prof_events.resize(2 * 1024);
+      for (auto& e : h->prof_events) HIP_TRY(hipEventCreate(&e));
+    }
+  });
 }
 
 // ---- point-sharded stepping ----

@@ -51,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("align_ms", C.c_double), ("loop_ms", C.c_double), ("pass_ms_total", C.c_double), ("passes", C.c_int),
                 ("outer_iterations", C.c_int), ("lm_trials", C.c_int), ("mean_candidates", C.c_double), ("valid_fraction", C.c_double),
                 ("index_build_ms", C.c_double), ("covariance_ms", C.c_double), ("upload_ms", C.c_double), ("voxel_size", C.c_double),
-                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int)]
+                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -331,6 +331,9 @@ class NanoGICP:
         if n.value:
             self._ck(self._L.ngicp_get_lm_trace(self._h, _p(out, c_f64p), n.value, C.byref(n)))
         return out
+
+    def setProfiling(self, on: bool):
+        self._ck(self._L.ngicp_set_profiling(self._h, 1 if on else 0))
 
     def stats(self) -> dict:
         s = Stats()

@@ -140,7 +140,8 @@ int ngicp_get_lm_trace(ngicp_t* h, double* rows8_or_null, size_t max_rows, size_
 typedef struct ngicp_stats {
   double align_ms;          /* host wall time of the last ngicp_align() */
   double loop_ms;           /* device time (HIP events on the handle's stream) of the iteration loop */
-  double pass_ms_total;     /* device time summed over the per-iteration kernels of the last align */
+  double pass_ms_total;     /* device time (HIP events on the handle's stream) summed over the k_gicp_pass launches of the
+                               last align that did work; only collected while ngicp_set_profiling(h, 1) */
   int passes;               /* per-iteration kernels launched that did work (= linearisations incl. the speculative last one) */
   int outer_iterations;     /* nr_iterations_ + 1 */
   int lm_trials;            /* LM trials evaluated */
@@ -152,9 +153,11 @@ typedef struct ngicp_stats {
   double voxel_size;        /* target grid voxel edge in use */
   int grid_dims[3];
   int lanes_per_query;
+  int passes_timed;         /* launches covered by pass_ms_total */
+  long long n_src, n_tgt;   /* cloud sizes of the last align */
 } ngicp_stats;
 int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
-/* collect per-kernel HIP-event timing inside align (adds event overhead; off by default) */
+/* HIP-event timing of every k_gicp_pass launch inside align (two event records per launch; off by default) */
 int ngicp_set_profiling(ngicp_t* h, int on);
 
 /* --- point-sharded multi-GPU stepping ------------------------ */
