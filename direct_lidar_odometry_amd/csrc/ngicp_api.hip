@@ -81,6 +81,11 @@ struct DeviceCloud {
   DevBuf inv_perm;    // int[n]    original index -> sorted position (lazily built)
   bool has_inv = false;
   DevBuf cell_start;  // int[ncells + 1]
+  DevBuf qpts;        // float4[n]  the points in Morton-tile query order, w = sorted position
+  DevBuf batches;     // int2[n_batches] {first qpts index, count <= 32}: tile-aligned query batches
+  DevBuf n_batches_dev;
+  DevBuf batch_boxes; // float[n_batches][6] centre + half extents of each batch (cloud frame)
+  int n_batches = 0;
   Grid grid{};
   double build_ms = 0.0;
 };
@@ -137,7 +142,8 @@ struct ngicp {
   double voxel_size = 0.0;  // 0 = auto
   int lanes_per_query = 0;  // 0 = auto
   double target_occupancy = 8.0;
-  int max_blocks = 1024;    // pass-kernel grid cap: 4 blocks x 256 CUs
+  int stage_grow = 6;       // upper limit of rings served from the LDS stage
+  int max_blocks = 2048;    // pass-kernel grid cap (one 32-query batch per wave up to 8192 batches)
   bool profiling = false;
 
   Slot src, tgt;
@@ -145,6 +151,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
+  DevBuf dbg;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
@@ -292,6 +299,43 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
                      h->fill.as<int>(), h->tmp.as<float4>());
   hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cell_start.as<int>(), dc->sorted.as<float4>(),
                      dc->perm.as<int>());
+  {
+    // query order (Morton over tiles of 2^shift cells; <= 128 tiles per axis => <= 2M histogram bins)
+    int shift = 2;
+    while (((std::max(g.nx, std::max(g.ny, g.nz)) - 1) >> shift) >= 128) ++shift;
+    int bits = 1;
+    while ((1 << bits) <= ((std::max(g.nx, std::max(g.ny, g.nz)) - 1) >> shift)) ++bits;
+    const int nbins = 1 << (3 * bits);
+    h->counts.ensure((size_t)(nbins + 1) * sizeof(int));
+    h->fill.ensure((size_t)(nbins + 1) * sizeof(int));  // reused as tile_start
+    HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(nbins + 1) * sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_tile_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni, g, shift, h->counts.as<int>());
+    const int ntiles = (nbins + kScanTile - 1) / kScanTile;
+    h->tile_sums.ensure((size_t)ntiles * sizeof(int));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)nullptr,
+                       (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), h->fill.as<int>());
+    dc->qpts.ensure(n * sizeof(float4));
+    hipLaunchKernelGGL(k_tile_place, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni, g, shift, dc->cell_start.as<int>(),
+                       h->fill.as<int>(), dc->qpts.as<float4>());
+    // tile-aligned query batches
+    h->keys.ensure((size_t)(nbins + 1) * sizeof(int));   // batches per tile
+    h->tmp.ensure((size_t)(nbins + 1) * sizeof(int));    // exclusive scan of it
+    dc->batches.ensure((n + 1) * sizeof(int2));
+    dc->n_batches_dev.ensure(sizeof(int));
+    hipLaunchKernelGGL(k_batch_count, dim3((nbins + 255) / 256), dim3(256), 0, h->stream, h->counts.as<int>(), nbins, h->keys.as<int>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->keys.as<int>(), nbins, h->tile_sums.as<int>(), (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)nullptr,
+                       (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->keys.as<int>(), nbins, h->tile_sums.as<int>(), h->tmp.as<int>());
+    hipLaunchKernelGGL(k_batch_fill, dim3((nbins + 255) / 256), dim3(256), 0, h->stream, h->counts.as<int>(), h->fill.as<int>(), h->tmp.as<int>(), nbins,
+                       dc->batches.as<int2>(), dc->n_batches_dev.as<int>());
+    dc->batch_boxes.ensure((n + 1) * 6 * sizeof(float));
+    hipLaunchKernelGGL(k_batch_boxes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dc->qpts.as<float4>(), dc->batches.as<int2>(), dc->n_batches_dev.as<int>(),
+                       dc->batch_boxes.as<float>());
+    HIP_TRY(hipMemcpyAsync(&dc->n_batches, dc->n_batches_dev.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(hipEventRecord(h->ev_b, h->stream));
   HIP_TRY(hipEventSynchronize(h->ev_b));
   float ms = 0.f;
@@ -413,13 +457,8 @@ void launch_pass_t(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s) {
 }
 
 void launch_pass(ngicp* h, const PassArgs& a, int lanes, int nblocks, hipStream_t s) {
-  switch (lanes) {
-    case 1: launch_pass_t<1>(h, a, nblocks, s); break;
-    case 2: launch_pass_t<2>(h, a, nblocks, s); break;
-    case 4: launch_pass_t<4>(h, a, nblocks, s); break;
-    case 16: launch_pass_t<16>(h, a, nblocks, s); break;
-    default: launch_pass_t<8>(h, a, nblocks, s); break;
-  }
+  (void)lanes;
+  launch_pass_t<2>(h, a, nblocks, s);
 }
 
 struct LoopCtx {
@@ -443,12 +482,11 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
     h->mahal[i].ensure(n * 6 * sizeof(double));
   }
   int lanes = h->lanes_per_query > 0 ? h->lanes_per_query : auto_lanes(n);
-  if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16) lanes = 8;
+  if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16) lanes = 4;
   const int groups_per_block = 256 / lanes;
   (void)groups_per_block;
-  const int groups = 64 / lanes;
-  const int batch = groups > 16 ? groups : 16;  // queries per wave batch (k_gicp_pass)
-  int nblocks = pick_blocks((n + batch - 1) / batch, 4, h->max_blocks);
+  lanes = 2;  // the staged kernel is built for 32-query batches (2 lanes per query)
+  int nblocks = pick_blocks((size_t)S.n_batches, 4, h->max_blocks);
   h->partials.ensure((size_t)kNumSlots * h->max_blocks * sizeof(double));
   h->state.ensure(sizeof(LmState));
   const int max_rows = std::max(1, h->p.max_iter) * std::max(1, h->p.lm_max_iter) + 1;
@@ -456,7 +494,10 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   h->sums.ensure(kPartialStride * sizeof(double));
 
   PassArgs& a = c.pa;
-  a.src = S.sorted.as<float4>();
+  a.qpts = S.qpts.as<float4>();
+  a.batches = S.batches.as<int2>();
+  a.batch_boxes = S.batch_boxes.as<float>();
+  a.n_batches = S.n_batches;
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
   a.n_src = (int)n;
   a.tgt = T.sorted.as<float4>();
@@ -477,6 +518,13 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.partials = h->partials.as<double>();
   a.partial_pitch = h->max_blocks;
   a.mode = 3;
+  a.dbg_stamps = nullptr;
+  {
+    // rings worth staging: enough to cover the distance gate (the search never looks farther), at most kStageMaxGrow
+    int need = kStageMaxGrow;
+    if (h->p.max_corr_dist < 1e30) need = (int)std::ceil(h->p.max_corr_dist / (double)T.grid.h);
+    a.stage_grow = h->stage_grow <= 0 ? 0 : std::max(1, std::min(std::min(kStageMaxGrow, h->stage_grow), need));  // 0: search straight from global memory
+  }
 
   SolveArgs& s = c.sa;
   s.st = a.st;
@@ -557,6 +605,12 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   if (h->p.max_iter <= 0) st.hot.done = 1;
   HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
 
+  const char* stamp_path = std::getenv("NGICP_DEBUG_STAMPS");  // diagnostic only
+  if (stamp_path) {
+    h->dbg.ensure((size_t)c.nblocks * 4 * 16 * sizeof(unsigned long long));
+    HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)c.nblocks * 4 * 16 * sizeof(unsigned long long), h->stream));
+    c.pa.dbg_stamps = h->dbg.as<unsigned long long>();
+  }
   const long max_passes = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? (long)h->p.max_iter : (long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1;
   const int chunk = 4;
   HIP_TRY(hipEventRecord(h->ev_a, h->stream));
@@ -594,6 +648,14 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   float loop_ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&loop_ms, h->ev_a, h->ev_b));
 
+  if (stamp_path) {
+    std::vector<unsigned long long> hs((size_t)c.nblocks * 4 * 16);
+    HIP_TRY(hipMemcpy(hs.data(), h->dbg.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(stamp_path, "wb")) {
+      std::fwrite(hs.data(), sizeof(unsigned long long), hs.size(), f);
+      std::fclose(f);
+    }
+  }
   pose_to_colmajor_f(st.hot.x0, h->final_T);
   h->converged = st.hot.converged;
   h->nr_iterations = st.hot.nr_iterations;
@@ -633,6 +695,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   s.lm_trials = st.hot.n_trace;
   s.mean_candidates = st.hot.passes > 0 ? st.hot.cand_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
   s.valid_fraction = st.hot.passes > 0 ? st.hot.valid_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
+  s.staged_fraction = st.hot.passes > 0 ? st.hot.staged_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
   s.pass_ms_total = 0.0;
   if (h->profiling) {
     // HIP events on the handle's own stream around every pass launch that did work
@@ -736,6 +799,7 @@ int ngicp_create(int device, ngicp_t** out) {
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_LANES")) h->lanes_per_query = std::atoi(s);
+    if (const char* s = std::getenv("NGICP_STAGE_GROW")) h->stage_grow = std::max(0, std::min(kStageMaxGrow, std::atoi(s)));
     if (const char* s = std::getenv("NGICP_MAX_BLOCKS")) h->max_blocks = std::max(1, std::min(65536, std::atoi(s)));
     *out = h.release();
     return NGICP_OK;
@@ -989,8 +1053,8 @@ int ngicp_get_correspondences(ngicp_t* h, int* corr_out, float* sqd_out) {
     h->knn_idx.ensure(n * sizeof(int));
     h->knn_d2.ensure(n * sizeof(float));
     LmState* dst = h->state.as<LmState>();
-    hipLaunchKernelGGL(k_corr_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->corr[st.hot.cur].as<int>(), h->src.dev->sorted.as<float4>(),
-                       h->tgt.dev->sorted.as<float4>(), (int)n, h->knn_idx.as<int>(), sqd_out ? h->knn_d2.as<float>() : nullptr, dst->xi_f);
+    hipLaunchKernelGGL(k_corr_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->corr[st.hot.cur].as<int>(), h->src.dev->qpts.as<float4>(),
+                       h->src.dev->sorted.as<float4>(), h->tgt.dev->sorted.as<float4>(), (int)n, h->knn_idx.as<int>(), sqd_out ? h->knn_d2.as<float>() : nullptr, dst->xi_f);
     HIP_TRY(hipMemcpyAsync(corr_out, h->knn_idx.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (sqd_out) HIP_TRY(hipMemcpyAsync(sqd_out, h->knn_d2.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

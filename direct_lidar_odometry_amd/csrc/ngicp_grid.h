@@ -250,4 +250,96 @@ __global__ void __launch_bounds__(256) k_cell_rank(const float4* __restrict__ tm
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Query order: the same points again, ordered by the Morton code of their 2^shift-cell tile (and by
+// linear cell, then sorted position, inside a tile).  Batches of consecutive queries are then compact
+// 3-D blobs, which is what lets a wave stage ONE small target region in LDS for the whole batch.
+// qpts[i] = {x, y, z, bitcast(sorted position)}.  Built without a sort: a point's destination is
+// tile_start[tile] + (points of the tile's cells that precede its cell) + (rank inside its cell).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int spread3(unsigned int v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__device__ __forceinline__ unsigned int tile_key(int cx, int cy, int cz, int shift) {
+  return spread3((unsigned)(cx >> shift)) | (spread3((unsigned)(cy >> shift)) << 1) | (spread3((unsigned)(cz >> shift)) << 2);
+}
+
+__global__ void __launch_bounds__(256) k_tile_count(const float4* __restrict__ sorted, int n, Grid g, int shift, int* __restrict__ tile_counts) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const float4 q = sorted[p];
+    int cx, cy, cz;
+    cell_coords(g, q.x, q.y, q.z, cx, cy, cz);
+    atomicAdd(&tile_counts[tile_key(cx, cy, cz, shift)], 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tile_place(const float4* __restrict__ sorted, int n, Grid g, int shift, const int* __restrict__ cell_start,
+                                                     const int* __restrict__ tile_start, float4* __restrict__ qpts) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const float4 q = sorted[p];
+    int cx, cy, cz;
+    cell_coords(g, q.x, q.y, q.z, cx, cy, cz);
+    const int ts = 1 << shift;
+    const int x0 = (cx >> shift) << shift, y0 = (cy >> shift) << shift, z0 = (cz >> shift) << shift;
+    const int x1 = min(x0 + ts, g.nx);  // exclusive
+    int before = 0;
+    for (int z = z0; z <= cz; ++z) {
+      const int ylast = (z == cz) ? cy : min(y0 + ts, g.ny) - 1;
+      for (int y = y0; y <= ylast; ++y) {
+        const int row = (z * g.ny + y) * g.nx;
+        const int xe = (z == cz && y == cy) ? cx : x1;  // own row: only the cells before the own cell
+        before += cell_start[row + xe] - cell_start[row + x0];
+      }
+    }
+    const int own = cell_start[(cz * g.ny + cy) * g.nx + cx];
+    const int dst = tile_start[tile_key(cx, cy, cz, shift)] + before + (p - own);
+    qpts[dst] = make_float4(q.x, q.y, q.z, __int_as_float(p));
+  }
+}
+
+// Query batches: runs of at most kBatchQueries consecutive entries of qpts that never cross a tile
+// boundary, so a batch's bounding box is at most one tile.  batch[b] = {first qpts index, count}.
+constexpr int kBatchQueries = 32;
+
+__global__ void __launch_bounds__(256) k_batch_count(const int* __restrict__ tile_counts, int nbins, int* __restrict__ nb) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nbins) nb[t] = (tile_counts[t] + kBatchQueries - 1) / kBatchQueries;
+}
+__global__ void __launch_bounds__(256) k_batch_fill(const int* __restrict__ tile_counts, const int* __restrict__ tile_start, const int* __restrict__ batch_start,
+                                                     int nbins, int2* __restrict__ batches, int* __restrict__ n_batches) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbins) return;
+  const int cnt = tile_counts[t];
+  const int b0 = batch_start[t], q0 = tile_start[t];
+  for (int j = 0, done = 0; done < cnt; ++j, done += kBatchQueries) batches[b0 + j] = make_int2(q0 + done, min(kBatchQueries, cnt - done));
+  if (t == nbins - 1) *n_batches = b0 + (cnt + kBatchQueries - 1) / kBatchQueries;
+}
+
+// Axis-aligned bounding box (metric, cloud frame) of every query batch: {cx, cy, cz, hx, hy, hz} centre and
+// half extents.  The pass kernel transforms it with the trial pose instead of reducing over lanes.
+__global__ void __launch_bounds__(256) k_batch_boxes(const float4* __restrict__ qpts, const int2* __restrict__ batches, const int* __restrict__ n_batches,
+                                                      float* __restrict__ boxes6) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= *n_batches) return;
+  const int2 bd = batches[b];
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int j = 0; j < bd.y; ++j) {
+    const float4 p = qpts[bd.x + j];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+  float* o = boxes6 + (size_t)b * 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    o[d] = 0.5f * (mn[d] + mx[d]);
+    o[3 + d] = 0.5f * (mx[d] - mn[d]);
+  }
+}
+
 }  // namespace ngk

@@ -27,7 +27,7 @@ namespace ngk {
 
 constexpr int kPartialStride = 32;  // doubles per block partial: 21 H + 6 b + y0 + yi (+3 pad)
 constexpr int kNumSums = 29;
-constexpr int kNumSlots = 31;      // + candidates tested, valid correspondences (exact integers carried as doubles)
+constexpr int kNumSlots = 32;      // + candidates tested, valid correspondences, queries served from the LDS stage (exact integers carried as doubles)
 constexpr int kTraceCols = 8;
 
 struct LmConfig {
@@ -52,6 +52,7 @@ struct LmHot {
   double lambda, nu;
   double cand_total;   // sum over passes of target points distance-tested
   double valid_total;  // sum over passes of gated-in correspondences
+  double staged_total; // sum over passes of queries whose rings 0..grow came from the LDS stage
   int iter;       // outer iteration index i (impl/lsq_registration_impl.hpp:101-102)
   int trial;      // LM trial index
   int have_lin;   // 0 until the first linearisation exists
@@ -70,7 +71,10 @@ struct LmState {
 };
 
 struct PassArgs {
-  const float4* src;        // sorted source points
+  const float4* qpts;       // source points in Morton-tile query order, w = sorted source position
+  const int2* batches;      // tile-aligned query batches {first qpts index, count <= 32}
+  const float* batch_boxes; // [n_batches][6] centre + half extents of each batch in the source frame
+  int n_batches;
   const double* cov_src;    // [n][6], source sorted order
   int n_src;
   const float4* tgt;        // sorted target points
@@ -85,6 +89,8 @@ struct PassArgs {
   double* partials;         // [kNumSlots][partial_pitch], slot-major
   int partial_pitch;        // >= gridDim.x
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
+  int stage_grow;           // rings served from the LDS stage (0: none)
+  unsigned long long* dbg_stamps;  // diagnostic build only: [wave][16] s_memtime stamps, or null
 };
 
 // --- cooperative exact 1-NN ------------------------------------------------------------------
@@ -102,18 +108,24 @@ __device__ __forceinline__ void group_min(float& d, int& p) {
 
 // Scan one contiguous run of sorted target points (used by the rare outer shells).  Loads are issued
 // four at a time so that four memory latencies overlap; the tail batch re-reads the run's last point
-// (a duplicate can never win because the comparison is strict), so no per-load predicate is needed.
+// (a duplicate can never win: equal distance AND equal position), so no per-load predicate is needed.
+// Nearest-neighbour candidates are ranked by (squared distance, sorted target position).  The reference
+// keeps the first point its kd-tree visits among exactly equidistant ones (impl/nanoflann_impl.hpp:184-211),
+// which no other index can mirror (SURVEY.md §7 "Ties"); a total order makes the winner independent of how
+// rows are dealt to lanes and of whether a candidate came from LDS or from global memory.
+__device__ __forceinline__ bool nn_better(float d, int p, float best, int bestp) { return d < best || (d == best && (unsigned)p < (unsigned)bestp); }
+
 __device__ __forceinline__ void scan_run_nn(const float4* __restrict__ tgt, int s, int e, float qx, float qy, float qz, float& best, int& pos) {
   const int last = e - 1;
   for (int p = s; p < e; p += 4) {
     const int p1 = min(p + 1, last), p2 = min(p + 2, last), p3 = min(p + 3, last);
     const float4 c0 = tgt[p], c1 = tgt[p1], c2 = tgt[p2], c3 = tgt[p3];
     const float d0 = sqdist(qx, qy, qz, c0), d1 = sqdist(qx, qy, qz, c1), d2 = sqdist(qx, qy, qz, c2), d3 = sqdist(qx, qy, qz, c3);
-    // strict '<': first visited wins among equals (impl/nanoflann_impl.hpp:184-211,1368)
-    if (d0 < best) { best = d0; pos = p; }
-    if (d1 < best) { best = d1; pos = p1; }
-    if (d2 < best) { best = d2; pos = p2; }
-    if (d3 < best) { best = d3; pos = p3; }
+    // total order (distance, sorted position): the winner does not depend on the visiting order
+    if (nn_better(d0, p, best, pos)) { best = d0; pos = p; }
+    if (nn_better(d1, p1, best, pos)) { best = d1; pos = p1; }
+    if (nn_better(d2, p2, best, pos)) { best = d2; pos = p2; }
+    if (nn_better(d3, p3, best, pos)) { best = d3; pos = p3; }
   }
 }
 
@@ -133,7 +145,7 @@ __device__ __forceinline__ void scan_runs_merged(const float4* __restrict__ tgt,
     float4 c[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) {
-      const int g = min(f + j, total - 1);  // the tail repeats the last candidate (strict '<' ignores it)
+      const int g = min(f + j, total - 1);  // the tail repeats the last candidate (same distance and position: ignored)
       int p = rs[0] + g;
 #pragma unroll
       for (int k = 1; k < NR; ++k) p = (g >= off[k]) ? rs[k] + (g - off[k]) : p;
@@ -143,7 +155,7 @@ __device__ __forceinline__ void scan_runs_merged(const float4* __restrict__ tgt,
 #pragma unroll
     for (int j = 0; j < W; ++j) {
       const float d = sqdist(qx, qy, qz, c[j]);
-      if (d < best) {
+      if (nn_better(d, idx[j], best, pos)) {
         best = d;
         pos = idx[j];
       }
@@ -151,37 +163,15 @@ __device__ __forceinline__ void scan_runs_merged(const float4* __restrict__ tgt,
   }
 }
 
-// G lanes (sub = 0..G-1) search the nearest target point of q.  All G lanes return the same result.
-// Rows (fixed y,z; contiguous in x) are dealt round-robin to the lanes of the group and every lane
-// walks its own rows, so the lanes of a group — and the groups of a wave — scan concurrently.
+// Outer shells (Chebyshev radius > rdone) straight from global memory; continues from the (best, pos)
+// found in rings 0..rdone until the exactness bound or the distance gate ends the search.  The row bounds of
+// a shell are fetched in chunks of 8 rows before any row is scanned: most shell rows are empty, so a lane
+// pays one memory round trip per chunk instead of two per row.
 template <int G>
-__device__ __forceinline__ void nn_search(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                          float gate_sq_f, int sub, float& best, int& pos, unsigned int& ncand) {
-  best = 3.4028234664e38f;
-  pos = -1;
-  int cx, cy, cz;
-  cell_coords(g, qx, qy, qz, cx, cy, cz);
+__device__ __forceinline__ void nn_shells(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                          int cx, int cy, int cz, float gate_sq_f, int sub, int rdone, float& best, int& pos, unsigned int& ncand) {
   const int rmax = max(max(g.nx, g.ny), g.nz);
-  // ring 0 and ring 1 together: 9 rows of up to 3 contiguous cells
-  {
-    constexpr int NR = (9 + G - 1) / G;
-    const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-    int rs[NR], re[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {  // all row bounds first: the cell_start latencies overlap
-      const int t = sub + k * G;
-      const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-      const bool ok = (t < 9) && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
-      const int row = ok ? (z * g.ny + y) * g.nx : 0;
-      const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
-      rs[k] = ok ? s : 0;
-      re[k] = ok ? e : 0;
-      ncand += (unsigned)(re[k] - rs[k]);
-    }
-    scan_runs_merged<NR, 8>(tgt, rs, re, qx, qy, qz, best, pos);
-  }
-  if (G > 1) group_min<G>(best, pos);
-  for (int r = 1;; ++r) {
+  for (int r = rdone;; ++r) {
     const float bound = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r);
     if (best <= bound || bound >= gate_sq_f || r >= rmax) break;
     // shell r + 1: rows t = sub, sub + G, ... of the (2R+1)^2 (y,z) window clipped to the grid
@@ -189,26 +179,58 @@ __device__ __forceinline__ void nn_search(const Grid& g, const float4* __restric
     const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
     const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
     const int xa = max(cx - R, 0), xb = min(cx + R, g.nx - 1);
+    const bool lo = cx - R >= 0, hi = cx + R <= g.nx - 1;
     const int wy = y1 - y0 + 1;
     const int nrows = wy * (z1 - z0 + 1);
-    for (int t = sub; t < nrows; t += G) {
-      const int z = z0 + t / wy, y = y0 + t % wy;
-      const int row = (z * g.ny + y) * g.nx;
-      if (z == cz - R || z == cz + R || y == cy - R || y == cy + R) {
-        const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
-        ncand += (unsigned)(e - s);
-        scan_run_nn(tgt, s, e, qx, qy, qz, best, pos);
-      } else {
-        const bool lo = cx - R >= 0, hi = cx + R <= g.nx - 1;
-        const int s0 = lo ? cell_start[row + cx - R] : 0, e0 = lo ? cell_start[row + cx - R + 1] : 0;
-        const int s1 = hi ? cell_start[row + cx + R] : 0, e1 = hi ? cell_start[row + cx + R + 1] : 0;
-        ncand += (unsigned)(e0 - s0) + (unsigned)(e1 - s1);
-        scan_run_nn(tgt, s0, e0, qx, qy, qz, best, pos);
-        scan_run_nn(tgt, s1, e1, qx, qy, qz, best, pos);
+    for (int t0 = sub; t0 < nrows; t0 += 8 * G) {
+      int s0[8], e0[8], s1[8], e1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * G;
+        const bool ok = t < nrows;
+        const int z = z0 + (ok ? t : 0) / wy, y = y0 + (ok ? t : 0) % wy;
+        const int row = (z * g.ny + y) * g.nx;
+        const bool face = z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+        // face rows: one run [xa, xb]; interior rows: the two end cells
+        const int a0 = face ? xa : cx - R, a1 = face ? xb + 1 : cx - R + 1;
+        const bool use0 = ok && (face || lo), use1 = ok && !face && hi;
+        s0[u] = use0 ? cell_start[row + a0] : 0;
+        e0[u] = use0 ? cell_start[row + a1] : 0;
+        s1[u] = use1 ? cell_start[row + cx + R] : 0;
+        e1[u] = use1 ? cell_start[row + cx + R + 1] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        ncand += (unsigned)(e0[u] - s0[u]) + (unsigned)(e1[u] - s1[u]);
+        if (e0[u] > s0[u]) scan_run_nn(tgt, s0[u], e0[u], qx, qy, qz, best, pos);
+        if (e1[u] > s1[u]) scan_run_nn(tgt, s1[u], e1[u], qx, qy, qz, best, pos);
       }
     }
     if (G > 1) group_min<G>(best, pos);
   }
+}
+
+// Rings 0..1 straight from global memory (fallback when a batch's region does not fit the LDS stage):
+// rows (fixed y,z; contiguous in x) are dealt round-robin to the G lanes of the group.
+template <int G>
+__device__ __forceinline__ void nn_ring1_global(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                                int cx, int cy, int cz, int sub, float& best, int& pos, unsigned int& ncand) {
+  constexpr int NR = (9 + G - 1) / G;
+  const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
+  int rs[NR], re[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {  // all row bounds first: the cell_start latencies overlap
+    const int t = sub + k * G;
+    const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+    const bool ok = (t < 9) && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+    const int row = ok ? (z * g.ny + y) * g.nx : 0;
+    const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
+    rs[k] = ok ? s : 0;
+    re[k] = ok ? e : 0;
+    ncand += (unsigned)(re[k] - rs[k]);
+  }
+  scan_runs_merged<NR, 8>(tgt, rs, re, qx, qy, qz, best, pos);
+  if (G > 1) group_min<G>(best, pos);
 }
 
 // --- reductions --------------------------------------------------------------------------------
@@ -219,20 +241,71 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // --- the fused pass ------------------------------------------------------------------------------
-// Work decomposition: a wave owns batches of B consecutive (cell-sorted) source points.
-//   phase 1  search: 64/G groups of G lanes each search one query; B*G/64 rounds cover the batch;
-//            the winning (distance, position) of query l is handed to lane l by a wave shuffle;
-//   phase 2  FP64 tail on lanes 0..B-1, one query per lane: K4 error under the previous
-//            correspondences, gate, Mahalanobis, residual/Jacobian/normal equations.
-// Waves never synchronise with each other inside the loop; the only barrier is the final
-// block-level reduction.  partials are stored slot-major ([slot][block]) so that the solver's
-// reduction reads them coalesced.
+// Work decomposition: a wave owns tile-aligned batches of up to 32 consecutive queries in Morton-tile
+// order (a compact 3-D blob; batches are cut at index-build time so that none leaves its tile).  Per batch:
+//   stage    the wave computes the batch's bounding box in target-cell coordinates, grows it by as many
+//            rings as fit (up to the number that covers the distance gate), and copies the NON-EMPTY (y,z)
+//            rows of that region into its private LDS slice: a row is ONE contiguous run of the cell-sorted
+//            target, moved by LDS-DMA (global_load_lds_dwordx4: no registers, all rows in flight together).
+//            The global reads of the search are two dependent round trips (row bounds; then points + the
+//            inner box's cell offsets), all wide and issued back to back;
+//   search   2 lanes per query scan the query's 27 cells out of LDS (ds_read_b128).  A query whose nearest
+//            point is not provably inside ring 1 then scans the staged rows that can still hold a closer
+//            point (row-level distance pruning; the list of non-empty rows is in LDS, so empty space costs
+//            nothing), which is exact for every ring the stage covers.  Only queries that need rings beyond
+//            the stage (dense regions that overflowed it) touch global memory in the search;
+//   tail     lanes 0..31, one query each, FP64: K4 error under the previous correspondences, gate,
+//            Mahalanobis, residual / Jacobian / normal equations.
+// Waves never synchronise with each other inside the loop; the only barrier is the final block-level
+// reduction.  Partials are stored slot-major ([slot][block]) so the solver reads them coalesced.
+constexpr int kStageCap = 768;       // target points per wave stage (12 KB)
+constexpr int kStageRowsPerLane = 4;
+constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
+constexpr int kStageXs = 20;         // cells per row of the staged region
+constexpr int kStageMaxGrow = 6;
+constexpr int kInnerRows = 100;      // rows of the inner box (query cells +- 1): 10 x 10
+constexpr int kInnerXs = 15;         // its cells per row (16 offsets = 16 lanes)
+
+struct WaveStage {
+  float4 pts[kStageCap];   // staged target points (as stored: w = original index); reused by the final reduction
+  int4 live[kStageRows];   // one record per NON-EMPTY row: {y | z << 16, lds_begin | lds_end << 16, global_pos - lds_pos, 0}
+  unsigned short row_live[kStageRows];                   // region row -> index into live[], 0xffff = empty row
+  unsigned short cell_off[kInnerRows * (kInnerXs + 1)];  // inner box: LDS position of the first point of each cell
+  int alloc;               // bump allocator of pts[]
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Scan staged LDS positions [ps, pe) of a row whose global position offset is `base` (pos = base + p).
+__device__ __forceinline__ void scan_stage_range(const WaveStage& S, int ps, int pe, int base, float qx, float qy, float qz, float& best, int& pos,
+                                                 unsigned int& ncand) {
+  ncand += (unsigned)(pe - ps);
+  for (int p = ps; p < pe; p += 4) {
+    const int p1 = min(p + 1, pe - 1), p2 = min(p + 2, pe - 1), p3 = min(p + 3, pe - 1);
+    const float4 a0 = S.pts[p], a1 = S.pts[p1], a2 = S.pts[p2], a3 = S.pts[p3];
+    const float d0 = sqdist(qx, qy, qz, a0), d1 = sqdist(qx, qy, qz, a1), d2 = sqdist(qx, qy, qz, a2), d3 = sqdist(qx, qy, qz, a3);
+    if (nn_better(d0, base + p, best, pos)) { best = d0; pos = base + p; }
+    if (nn_better(d1, base + p1, best, pos)) { best = d1; pos = base + p1; }
+    if (nn_better(d2, base + p2, best, pos)) { best = d2; pos = base + p2; }
+    if (nn_better(d3, base + p3, best, pos)) { best = d3; pos = base + p3; }
+  }
+}
+
+#define NG_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
 template <int G>
 __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
-  constexpr int GROUPS = 64 / G;
-  constexpr int B = GROUPS > 16 ? GROUPS : 16;
-  constexpr int ROUNDS = B / GROUPS;
+  constexpr int B = 64 / G;  // queries per wave batch
+  static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
+  __shared__ WaveStage stage_all[4];
   const LmState* __restrict__ st = a.st;
   if (!(a.mode & 4) && st->hot.done) return;
 
@@ -243,6 +316,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   const double* __restrict__ mahal_old = a.mahal[cur];
   int* __restrict__ corr_new = a.corr[nxt];
   double* __restrict__ mahal_new = a.mahal[nxt];
+  const Grid& g = a.grid;
 
   // trial pose (FP64) and its float cast
   double R[9], t[3];
@@ -257,24 +331,33 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   double acc[kNumSums];
 #pragma unroll
   for (int i = 0; i < kNumSums; ++i) acc[i] = 0.0;
-  unsigned int ncand = 0, nvalid = 0;
+  unsigned int ncand = 0, nvalid = 0, nstaged = 0;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, grp = lane / G;
-  const int nbatches = (a.n_src + B - 1) / B;
-  for (int batch = blockIdx.x * 4 + wave; batch < nbatches; batch += gridDim.x * 4) {
-    const int qbase = batch * B;
+  WaveStage& S = stage_all[wave];
+  NG_STAMP(0);
+  // XCD-aware work assignment: blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8, each
+  // with its own 4 MB L2), and batches are in Morton order, so XCD x takes the x-th contiguous eighth of the
+  // batch list: a compact part of space whose slice of the target index stays resident in that XCD's L2.
+  // (Speed only: any placement gives the same result.)
+  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * 4 + wave, slots = ((gridDim.x + 7 - xcd) >> 3) * 4;
+  const int chunk = (a.n_batches + 7) >> 3;
+  const int chunk_end = min((xcd + 1) * chunk, a.n_batches);
+  for (int batch = xcd * chunk + slot; batch < chunk_end; batch += slots) {
+    const int2 bd = a.batches[batch];
+    const int qbase = bd.x, qcount = bd.y;
     float mybest = 3.4028234664e38f;
     int mypos = -1;
     // operands of the FP64 tail that do not depend on the search are requested first, so that their
-    // latency hides behind phase 1
+    // latency hides behind the search
     const int i = qbase + lane;
-    const bool mine = lane < B && i < a.n_src;
+    const bool mine = lane < qcount;
     float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
     int j_old = -1;
     double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
     if (mine) {
-      sp = a.src[i];
+      sp = a.qpts[i];
       if (do_err) {
         j_old = corr_old[i];
         const double* M = mahal_old + (size_t)i * 6;
@@ -282,42 +365,222 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         for (int e = 0; e < 6; ++e) Mold[e] = M[e];
       }
       if (do_lin) {
-        const double* CA = a.cov_src + (size_t)i * 6;
+        const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;
 #pragma unroll
         for (int e = 0; e < 6; ++e) ca[e] = CA[e];
       }
     }
     float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine && j_old >= 0) bp_old = a.tgt[j_old];
+    NG_STAMP(1);
+
     if (do_lin && (a.mode & 8)) {  // DEBUG timing build: fake search result
       mypos = (qbase + lane) % 1000;
       mybest = 0.01f;
     } else if (do_lin) {
-      // ---- phase 1: K2 search (impl/nano_gicp_impl.hpp:178,190-192) ----
+      // ---- K2 (impl/nano_gicp_impl.hpp:178,190-192): the query of this lane's group ----
+      const int qi = qbase + grp;
+      const bool qok = grp < qcount;
+      float qx = 0.f, qy = 0.f, qz = 0.f;
+      int cx = 0, cy = 0, cz = 0;
+      if (qok) {
+        const float4 qp = a.qpts[qi];
+        // Eigen 4x4 * 4-vector in float: ((c0*x + c1*y) + c2*z) + c3*1
+        qx = ((Tf[0] * qp.x + Tf[1] * qp.y) + Tf[2] * qp.z) + Tf[3];
+        qy = ((Tf[4] * qp.x + Tf[5] * qp.y) + Tf[6] * qp.z) + Tf[7];
+        qz = ((Tf[8] * qp.x + Tf[9] * qp.y) + Tf[10] * qp.z) + Tf[11];
+        cell_coords(g, qx, qy, qz, cx, cy, cz);
+      }
+      float best = 3.4028234664e38f;
+      int pos = -1;
+      NG_STAMP(2);
+      // ---- stage the batch's region.  Its bounding box comes from the batch's precomputed AABB pushed through
+      //      the trial pose (no cross-lane reduction); a batch never leaves one Morton tile, so it is bounded. ----
+      int b0x, b0y, b0z, b1x, b1y, b1z;
+      {
+        const float* bb = a.batch_boxes + (size_t)batch * 6;
+        const float bcx = bb[0], bcy = bb[1], bcz = bb[2], bhx = bb[3], bhy = bb[4], bhz = bb[5];
+        const float mx = ((Tf[0] * bcx + Tf[1] * bcy) + Tf[2] * bcz) + Tf[3];
+        const float my = ((Tf[4] * bcx + Tf[5] * bcy) + Tf[6] * bcz) + Tf[7];
+        const float mz = ((Tf[8] * bcx + Tf[9] * bcy) + Tf[10] * bcz) + Tf[11];
+        const float pad = 1e-3f * g.h;
+        const float ex = (fabsf(Tf[0]) * bhx + fabsf(Tf[1]) * bhy) + fabsf(Tf[2]) * bhz + pad + 4e-6f * (fabsf(mx) + bhx + bhy + bhz);
+        const float ey = (fabsf(Tf[4]) * bhx + fabsf(Tf[5]) * bhy) + fabsf(Tf[6]) * bhz + pad + 4e-6f * (fabsf(my) + bhx + bhy + bhz);
+        const float ez = (fabsf(Tf[8]) * bhx + fabsf(Tf[9]) * bhy) + fabsf(Tf[10]) * bhz + pad + 4e-6f * (fabsf(mz) + bhx + bhy + bhz);
+        cell_coords(g, mx - ex, my - ey, mz - ez, b0x, b0y, b0z);
+        cell_coords(g, mx + ex, my + ey, mz + ez, b1x, b1y, b1z);
+      }
+      // inner box: box cells +- 1 (the ring-1 windows of every query of the batch)
+      const int iX0 = max(b0x - 1, 0), iY0 = max(b0y - 1, 0), iZ0 = max(b0z - 1, 0);
+      const int iX1 = min(b1x + 1, g.nx - 1), iY1 = min(b1y + 1, g.ny - 1), iZ1 = min(b1z + 1, g.nz - 1);
+      const int iwy = iY1 - iY0 + 1, irows = iwy * (iZ1 - iZ0 + 1), iXS = iX1 - iX0 + 1;
+      int X0 = 0, Y0 = 0, Z0 = 0, wy = 1, grow = 0;
+      bool staged = false;
+      if (a.stage_grow >= 1 && irows <= kInnerRows && iXS <= kInnerXs) {
+        const int bmax = max(max(b1x - b0x, b1y - b0y), b1z - b0z) + 1;
+        grow = a.stage_grow;
+        for (int attempt = 0; attempt < 3 && grow >= 1 && !staged; ++attempt) {
+          int XS, rows;
+          for (;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
+            X0 = max(b0x - grow, 0);
+            Y0 = max(b0y - grow, 0);
+            Z0 = max(b0z - grow, 0);
+            const int X1 = min(b1x + grow, g.nx - 1), Y1 = min(b1y + grow, g.ny - 1), Z1 = min(b1z + grow, g.nz - 1);
+            XS = X1 - X0 + 1;
+            wy = Y1 - Y0 + 1;
+            rows = wy * (Z1 - Z0 + 1);
+            if ((rows <= kStageRows && XS <= kStageXs) || grow == 1) break;
+          }
+          if (rows > kStageRows || XS > kStageXs) break;
+          // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target
+          int rb[kStageRowsPerLane], rs[kStageRowsPerLane], rn[kStageRowsPerLane], ro[kStageRowsPerLane];
 #pragma unroll
-      for (int r = 0; r < ROUNDS; ++r) {
-        const int qi = qbase + r * GROUPS + grp;
-        float best = 3.4028234664e38f;
-        int pos = -1;
-        if (qi < a.n_src) {
-          const float4 qp = a.src[qi];
-          // Eigen 4x4 * 4-vector in float: ((c0*x + c1*y) + c2*z) + c3*1
-          const float qx = ((Tf[0] * qp.x + Tf[1] * qp.y) + Tf[2] * qp.z) + Tf[3];
-          const float qy = ((Tf[4] * qp.x + Tf[5] * qp.y) + Tf[6] * qp.z) + Tf[7];
-          const float qz = ((Tf[8] * qp.x + Tf[9] * qp.y) + Tf[10] * qp.z) + Tf[11];
-          nn_search<G>(a.grid, a.tgt, a.tgt_cell_start, qx, qy, qz, a.gate_sq_f, sub, best, pos, ncand);
-        }
-        // hand query (r*GROUPS + g)'s result to lane r*GROUPS + g
-        const int src_lane = (lane % GROUPS) * G;
-        const float gb = __shfl(best, src_lane);
-        const int gp = __shfl(pos, src_lane);
-        if (lane / GROUPS == r) {
-          mybest = gb;
-          mypos = gp;
+          for (int k = 0; k < kStageRowsPerLane; ++k) {
+            const int r = lane + 64 * k;
+            const bool has = r < rows;
+            rb[k] = has ? ((Z0 + r / wy) * g.ny + (Y0 + r % wy)) * g.nx + X0 : 0;
+            const int sv = has ? a.tgt_cell_start[rb[k]] : 0, ev = has ? a.tgt_cell_start[rb[k] + XS] : 0;
+            rs[k] = sv;
+            rn[k] = ev - sv;
+          }
+          wave_lds_sync();  // the previous batch's (or attempt's) readers are done with the slice
+          if (lane == 0) S.alloc = 0;
+          wave_lds_sync();
+          // LDS space for each non-empty row from a bump allocator (placement order is irrelevant: positions are
+          // mapped back to global sorted positions, and candidates are ranked by a total order)
+#pragma unroll
+          for (int k = 0; k < kStageRowsPerLane; ++k) ro[k] = rn[k] > 0 ? atomicAdd(&S.alloc, rn[k]) : 0;
+          wave_lds_sync();
+          const int total = S.alloc;
+          if (total > kStageCap) {
+            if (grow == 1) break;
+            // surface-like data: the point count scales with the region's face area
+            const float ratio = sqrtf(0.8f * (float)kStageCap / (float)total);
+            const int side = (int)((float)(bmax + 2 * grow) * ratio);
+            grow = max(1, min(grow - 1, (side - bmax) / 2));
+            continue;
+          }
+          staged = true;
+          int nlive = 0;
+#pragma unroll
+          for (int k = 0; k < kStageRowsPerLane; ++k) {
+            const int r = lane + 64 * k;
+            const unsigned long long live = __ballot(rn[k] > 0);
+            if (rn[k] > 0) {
+              const int li = nlive + __popcll(live & ((1ull << lane) - 1ull));
+              S.live[li] = make_int4((Y0 + r % wy) | ((Z0 + r / wy) << 16), ro[k] | ((ro[k] + rn[k]) << 16), rs[k] - ro[k], 0);
+              S.row_live[r] = (unsigned short)li;
+            } else if (r < rows) {
+              S.row_live[r] = 0xffffu;
+            }
+            nlive += __popcll(live);
+          }
+          // every NON-EMPTY row is one contiguous run -> LDS-DMA pieces, all in flight together; row parameters
+          // travel by v_readlane (no LDS or memory round trip in the issue loop).  Rows of the inner box also
+          // fetch their per-cell offsets (lanes along x); the stores are deferred so that the loads overlap.
+          int pend_i[4], pend_v[4], pend_o[4];
+          int npend = 0;
+#pragma unroll
+          for (int k = 0; k < kStageRowsPerLane; ++k) {
+            unsigned long long live = __ballot(rn[k] > 0);
+            while (live) {
+              const int rl = __builtin_ctzll(live);
+              live &= live - 1;
+              const int cnt = __builtin_amdgcn_readlane(rn[k], rl), src0 = __builtin_amdgcn_readlane(rs[k], rl);
+              const int dst0 = __builtin_amdgcn_readlane(ro[k], rl), base = __builtin_amdgcn_readlane(rb[k], rl);
+              for (int j0 = 0; j0 < cnt; j0 += 64) {
+                if (j0 + lane < cnt)
+                  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.tgt + src0 + j0 + lane),
+                                                   (void __attribute__((address_space(3)))*)(S.pts + dst0 + j0), 16, 0, 0);
+              }
+              const int r = rl + 64 * k;
+              const int y = Y0 + r % wy, z = Z0 + r / wy;
+              if (y >= iY0 && y <= iY1 && z >= iZ0 && z <= iZ1) {
+                pend_i[npend] = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
+                pend_o[npend] = dst0 - src0;
+                pend_v[npend] = (lane <= iXS) ? a.tgt_cell_start[base + (iX0 - X0) + lane] : 0;
+                if (++npend == 4) {
+#pragma unroll
+                  for (int u = 0; u < 4; ++u)
+                    if (lane <= iXS) S.cell_off[pend_i[u] + lane] = (unsigned short)(pend_v[u] + pend_o[u]);
+                  npend = 0;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < npend && lane <= iXS) S.cell_off[pend_i[u] + lane] = (unsigned short)(pend_v[u] + pend_o[u]);
+          if (lane == 0) S.alloc = nlive;  // from here on: the number of live rows
+          __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the DMA pieces have landed
+          wave_lds_sync();
         }
       }
+      NG_STAMP(3);
+      if (a.dbg_stamps && lane == 0) {
+        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
+        d[10] = (unsigned long long)(staged ? grow : 0);
+        d[11] = (unsigned long long)(staged ? S.alloc : 0);
+        d[12] = (unsigned long long)qcount;
+        d[13] = (unsigned long long)((b1x - b0x + 1) | ((b1y - b0y + 1) << 8) | ((b1z - b0z + 1) << 16));
+      }
+      if (qok) {
+        int rdone = 1;  // rings 0..rdone have been searched exhaustively
+        // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
+        // simply takes the global path
+        const bool in_box = staged && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
+        if (in_box) {
+          if (sub == 0) ++nstaged;
+          // ---- rings 0..1 out of LDS: lane `sub` takes rows sub, sub + G, ... of the 3 x 3 (y,z) window ----
+          const int c0 = max(cx - 1, 0) - iX0, c1 = min(cx + 1, g.nx - 1) - iX0 + 1;
+#pragma unroll
+          for (int k = 0; k < (9 + G - 1) / G; ++k) {
+            const int tt = sub + k * G;
+            const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
+            if (tt < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+              const int li = S.row_live[(z - Z0) * wy + (y - Y0)];
+              if (li != 0xffff) {  // empty rows carry no cell offsets
+                const int ci = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
+                scan_stage_range(S, S.cell_off[ci + c0], S.cell_off[ci + c1], S.live[li].z, qx, qy, qz, best, pos, ncand);
+              }
+            }
+          }
+          if (G > 1) group_min<G>(best, pos);
+          NG_STAMP(4);
+          // ---- rings 2..grow: the staged rows that can still hold a closer point ----
+          if (grow >= 2) {
+            const float bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
+            if (!(best <= bound1 || bound1 >= a.gate_sq_f)) {
+              const int nl = S.alloc;
+              for (int li = sub; li < nl; li += G) {
+                const int4 rec = S.live[li];
+                const int ry = rec.x & 0xffff, rz = rec.x >> 16;
+                // lower bound of the distance from q to anything in row (ry, rz): the (y,z) gap to its cells
+                float gy = 0.f, gz = 0.f;
+                if (ry > cy) gy = (g.oy + (float)ry * g.h) - qy; else if (ry < cy) gy = qy - (g.oy + (float)(ry + 1) * g.h);
+                if (rz > cz) gz = (g.oz + (float)rz * g.h) - qz; else if (rz < cz) gz = qz - (g.oz + (float)(rz + 1) * g.h);
+                gy = fmaxf(gy - g.slack, 0.f);
+                gz = fmaxf(gz - g.slack, 0.f);
+                if (gy * gy + gz * gz > best) continue;
+                scan_stage_range(S, rec.y & 0xffff, (int)((unsigned)rec.y >> 16), rec.z, qx, qy, qz, best, pos, ncand);
+              }
+              if (G > 1) group_min<G>(best, pos);
+              rdone = grow;
+            }
+          }
+        } else {
+          nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
+        }
+        NG_STAMP(5);
+        nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, rdone, best, pos, ncand);
+      }
+      NG_STAMP(6);
+      // hand query g's result to lane g
+      const int src_lane = (lane % B) * G;
+      mybest = __shfl(best, src_lane);
+      mypos = __shfl(pos, src_lane);
     }
-    // ---- phase 2: one query per lane ----
+    // ---- tail: one query per lane ----
     if ((a.mode & 16) && mine) {  // DEBUG timing build: skip the FP64 tail
       corr_new[i] = mypos;
       acc[27] += (double)mybest;
@@ -393,28 +656,41 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     }
   }
 
-  // ---- R0: wave shuffle -> LDS -> block partial (slot-major) ----
+  NG_STAMP(7);
+  // ---- R0: per-wave reduction through LDS (the stage slice is free now): lanes 0..31 hold the tail's sums ----
+  //      lane l writes row l of a [32][30] tile, lane v then adds column v in fixed order (deterministic);
+  //      a butterfly of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips
+  {
+    wave_lds_sync();
+    double* red = reinterpret_cast<double*>(S.pts);                       // [32][30] doubles
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(red + 32 * 30);  // [3][64] counters
+    if (lane < 32) {
 #pragma unroll
-  for (int v = 0; v < kNumSums; ++v) {
-    const double s = wave_sum(acc[v]);
-    if (lane == 0) lds[wave][v] = s;
+      for (int v = 0; v < kNumSums; ++v) red[lane * 30 + v] = acc[v];
+    }
+    cnt[lane] = ncand;
+    cnt[64 + lane] = nvalid;
+    cnt[128 + lane] = nstaged;
+    wave_lds_sync();
+    double out = 0.0;
+    if (lane < kNumSums) {
+      for (int l = 0; l < 32; ++l) out += red[l * 30 + lane];
+    } else if (lane < kNumSlots) {
+      unsigned int sum = 0;
+      for (int l = 0; l < 64; ++l) sum += cnt[(lane - kNumSums) * 64 + l];
+      out = (double)sum;
+    }
+    if (lane < kNumSlots) lds[wave][lane] = out;
   }
-  unsigned int c = ncand, nv = nvalid;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    c += __shfl_xor(c, o);
-    nv += __shfl_xor(nv, o);
-  }
-  if (lane == 0) {
-    lds[wave][29] = (double)c;
-    lds[wave][30] = (double)nv;
-  }
+  NG_STAMP(8);
   __syncthreads();
+  NG_STAMP(9);
   if (threadIdx.x < kNumSlots) {
     const int v = threadIdx.x;
     a.partials[(size_t)v * a.partial_pitch + blockIdx.x] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
   }
 }
+#undef NG_STAMP
 
 // Upper-triangular packing used by the pass: index of (r,c), r <= c, in the 21-vector
 __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
@@ -484,6 +760,7 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
   L.passes += 1;
   L.cand_total += sums[29];
   L.valid_total += sums[30];
+  L.staged_total += sums[31];
 
   if (cfg.optimizer == 0) {
     // ---- Gauss-Newton: impl/lsq_registration_impl.hpp:142-158, one pass per outer iteration ----
@@ -653,12 +930,13 @@ __global__ void __launch_bounds__(256) k_transform_out(const float4* __restrict_
 }
 
 // map correspondences (sorted source slot -> sorted target position) back to ORIGINAL indices
-__global__ void __launch_bounds__(256) k_corr_to_original(const int* __restrict__ corr, const float4* __restrict__ src_sorted, const float4* __restrict__ tgt_sorted,
-                                                           int n, int* __restrict__ out_corr, float* __restrict__ out_sqd, const float* __restrict__ xi_f) {
+__global__ void __launch_bounds__(256) k_corr_to_original(const int* __restrict__ corr, const float4* __restrict__ qpts, const float4* __restrict__ src_sorted,
+                                                           const float4* __restrict__ tgt_sorted, int n, int* __restrict__ out_corr, float* __restrict__ out_sqd,
+                                                           const float* __restrict__ xi_f) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float4 sp = src_sorted[i];
-  const int o = __float_as_int(sp.w);
+  const float4 sp = qpts[i];
+  const int o = __float_as_int(src_sorted[__float_as_int(sp.w)].w);
   const int j = corr[i];
   out_corr[o] = j >= 0 ? __float_as_int(tgt_sorted[j].w) : -1;
   if (out_sqd) {

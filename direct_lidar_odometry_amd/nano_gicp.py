@@ -51,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("align_ms", C.c_double), ("loop_ms", C.c_double), ("pass_ms_total", C.c_double), ("passes", C.c_int),
                 ("outer_iterations", C.c_int), ("lm_trials", C.c_int), ("mean_candidates", C.c_double), ("valid_fraction", C.c_double),
                 ("index_build_ms", C.c_double), ("covariance_ms", C.c_double), ("upload_ms", C.c_double), ("voxel_size", C.c_double),
-                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong)]
+                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong), ("staged_fraction", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

@@ -155,6 +155,7 @@ typedef struct ngicp_stats {
   int lanes_per_query;
   int passes_timed;         /* launches covered by pass_ms_total */
   long long n_src, n_tgt;   /* cloud sizes of the last align */
+  double staged_fraction;   /* fraction of queries whose inner rings were served from the LDS stage */
 } ngicp_stats;
 int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
 /* HIP-event timing of every k_gicp_pass launch inside align (two event records per launch; off by default) */
@@ -162,7 +163,7 @@ int ngicp_set_profiling(ngicp_t* h, int on);
 
 /* --- point-sharded multi-GPU stepping ------------------------ */
 /* One GICP pass over this handle's source block at the engine's current trial pose: writes 32 doubles
- * {H upper-tri 21, b 6, y0, yi, candidates tested, valid correspondences, 0} to device memory
+ * {H upper-tri 21, b 6, y0, yi, candidates tested, valid correspondences, staged queries} to device memory
  * `sums32_dev` (caller all-reduces them, e.g. RCCL via torch.distributed: 256 B, latency-bound), then
  * ngicp_sharded_step consumes the reduced sums and advances the LM state machine identically on every
  * rank.  *done is set when the alignment finished. */

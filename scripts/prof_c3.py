@@ -8,10 +8,10 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
 w = clouds.scan_to_submap(100_000, 5) if cfg == "c3" else (clouds.scan_to_scan(100_000) if cfg == "c2" else clouds.scan_to_submap(250_000, 8, shape="os1"))
 g = NanoGICP()
-g.setMaxCorrespondenceDistance(w.max_corr_dist)
+g.setMaxCorrespondenceDistance(float(os.environ.get("NGICP_GATE", w.max_corr_dist)))
 g.setMaximumIterations(20); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
 g.setInputTarget(w.target); g.setInputSource(w.source)
 g.calculateTargetCovariances(); g.calculateSourceCovariances()
 for r in range(reps):
     g.align(w.guess); s = g.stats()
-    print(f"align {s['align_ms']:.3f} ms loop {s['loop_ms']:.3f} passes {s['passes']} iters {s['outer_iterations']} Cbar {s['mean_candidates']:.1f} h {s['voxel_size']:.3f} lanes {s['lanes_per_query']}", flush=True)
+    print(f"align {s['align_ms']:.3f} ms loop {s['loop_ms']:.3f} passes {s['passes']} iters {s['outer_iterations']} Cbar {s['mean_candidates']:.1f} h {s['voxel_size']:.3f} lanes {s['lanes_per_query']} staged {s['staged_fraction']:.3f}", flush=True)

@@ -1,0 +1,34 @@
+import sys, numpy as np
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16).astype(np.float64)
+a = a[a[:, 0] > 0]
+t0 = a[:, 0].min()
+names = ["entry", "prologue loads", "query cells", "staged", "ring1 done", "far rows done", "shells done", "loop end", "reduce done", "barrier"]
+print("waves", len(a), " kernel span (cycles):", a[:, :10].max() - t0)
+print("wave start offset percentiles [0,50,90,100]:", np.percentile(a[:, 0] - t0, [0, 50, 90, 100]).round(0))
+prev = a[:, 0]
+for k in range(1, 10):
+    cur = a[:, k]
+    ok = cur > 0
+    d = (cur - prev)[ok]
+    if ok.sum():
+        print(f"{names[k]:16s} n={ok.sum():5d} delta cycles p10/p50/p90/max: {np.percentile(d,10):9.0f} {np.percentile(d,50):9.0f} {np.percentile(d,90):9.0f} {d.max():9.0f}")
+    prev = np.where(ok, cur, prev)
+life = a[:, 9] - a[:, 0]
+print("wave lifetime p10/p50/p90/max:", np.percentile(life, [10, 50, 90, 100]).round(0))
+
+g = a[:, 10]; nl = a[:, 11]; qc = a[:, 12]; bb = a[:, 13].astype(np.int64)
+print("grow histogram:", {int(k): int((g == k).sum()) for k in np.unique(g)})
+print("live rows p10/p50/p90/max:", np.percentile(nl, [10, 50, 90, 100]))
+print("queries per batch p10/p50/p90:", np.percentile(qc, [10, 50, 90]), "mean", qc.mean())
+print("box dims x/y/z median:", np.median(bb & 255), np.median((bb >> 8) & 255), np.median((bb >> 16) & 255), "max", (bb & 255).max(), ((bb >> 8) & 255).max(), ((bb >> 16) & 255).max())
+st = a[:, 3] - a[:, 2]
+for k in np.unique(g):
+    m = g == k
+    print(f"  grow {int(k)}: n={m.sum()} staging cycles median {np.median(st[m]):.0f} p90 {np.percentile(st[m], 90):.0f}; live rows median {np.median(nl[m]):.0f}; far-phase median {np.median((a[:,5]-a[:,4])[m]):.0f}")
+life = a[:, 8] - a[:, 0]
+order = np.argsort(-life)[:12]
+print("slowest waves: life | prologue, cells, stage, ring1, far, shells, tail, reduce | grow nlive qcount box")
+for w in order:
+    d = [a[w, k] - a[w, k - 1] if a[w, k] > 0 and a[w, k-1] > 0 else -1 for k in range(1, 9)]
+    print(int(life[w]), [int(x) for x in d], int(g[w]), int(nl[w]), int(qc[w]), (int(bb[w]) & 255, (int(bb[w]) >> 8) & 255, (int(bb[w]) >> 16) & 255))
+print("sum of wave lifetimes (to reduce-done):", life.sum(), " / 2048 slots =", life.sum() / 2048)
