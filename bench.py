@@ -66,19 +66,36 @@ def cpu_baseline(w, tgt_covs, src_covs):
     o.setSourceCovariances(src_covs); o.setTargetCovariances(tgt_covs)
     o.setMaximumIterations(2); o.align(w.guess)  # warm-up
     o.setMaximumIterations(GICP_ITERS)
-    done, aligns, budget_s = 0, 0, 4.0
-    t0 = time.perf_counter()
-    while True:
-        o.align(w.guess)
-        done += o.nr_iterations + 1
-        aligns += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or aligns >= 200:
-            break
-    return {"value": done / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "sample": f"{aligns} align() calls of the same 100k->500k workload ({done} outer GICP iterations, {dt:.1f} s wall = "
-                      f"{dt * threads:.0f} thread-seconds), OpenMP {threads} threads (host has {os.cpu_count()} cpus); "
-                      f"{dt * 1e3 / done:.2f} ms/iteration; serial kd-tree build of the 500k target ({build_s * 1e3:.0f} ms) not included",
+    # The reference takes omp_get_max_threads() (impl/nano_gicp_impl.hpp:51-55).  On a shared box that can
+    # oversubscribe this job's CPU share badly, so several thread counts are tried and the BEST one is reported.
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cands = sorted({min(c, threads) for c in (8, 16, 32, 64, 128, 256, avail)})
+    table, best = [], None
+    for nt in cands:
+        o.setNumThreads(nt)
+        o.align(w.guess)  # warm the thread pool at this width
+        done, aligns, budget_s = 0, 0, 2.0
+        t0 = time.perf_counter()
+        while True:
+            o.align(w.guess)
+            done += o.nr_iterations + 1
+            aligns += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or aligns >= 100:
+                break
+        rate = done / dt
+        table.append((nt, rate))
+        if best is None or rate > best[1]:
+            best = (nt, rate, done, aligns, dt)
+    nt, rate, done, aligns, dt = best
+    return {"value": rate, "unit": "iterations/s", "cores": nt, "kind": "port",
+            "sample": f"best of OpenMP thread counts {[(a, round(b, 1)) for a, b in table]} (threads, it/s); at {nt} threads: {aligns} align() calls of the "
+                      f"same 100k->500k workload ({done} outer GICP iterations, {dt:.1f} s wall); host reports {os.cpu_count()} cpus, "
+                      f"{avail} in this job's affinity mask, omp_get_max_threads() = {threads}; {dt * 1e3 / done:.2f} ms/iteration; serial kd-tree "
+                      f"build of the 500k target ({build_s * 1e3:.0f} ms) not included",
             "ms_per_iteration": dt * 1e3 / done, "ms_per_scan": dt * 1e3 / aligns, "target_index_build_ms": build_s * 1e3}, o.getFinalTransformation()
 
 

@@ -1,0 +1,72 @@
+"""Turn gpurun_out/prof_r01/* into the committed summaries under profiles/ (r01_*)."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r01")
+DST = os.path.join(ROOT, "profiles")
+os.makedirs(DST, exist_ok=True)
+
+def one(pattern):
+    fs = glob.glob(os.path.join(SRC, pattern))
+    return fs[0] if fs else None
+
+# 1. kernel stats (rocprofv3 --kernel-trace --stats)
+stats = one("trace/*/*kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(DST, "r01_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+# working launches of the pass kernel only (launches after `done` exit immediately: ~4 us)
+trace = one("trace/*/*kernel_trace.csv")
+durs = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+pass_name = next(k for k in durs if "k_gicp_pass" in k)
+work = [d for d in durs[pass_name] if d > 20.0]
+solve_name = next(k for k in durs if "k_lm_solve" in k)
+swork = [d for d in durs[solve_name] if d > 8.0]
+
+def pmc(dirname):
+    f = one(dirname + "/*/*counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+def work_mean(agg, kern_sub, counter):
+    for k, v in agg.items():
+        if kern_sub in k and counter in v:
+            vals = sorted(v[counter])
+            vals = vals[len(vals) // 3:]  # drop the early-exit launches (smallest third)
+            return sum(vals) / len(vals)
+    return None
+
+fetch = work_mean(pmc("pmc_fetch"), "k_gicp_pass", "FETCH_SIZE")
+write = work_mean(pmc("pmc_write"), "k_gicp_pass", "WRITE_SIZE")
+l2 = pmc("pmc_l2")
+sq = pmc("pmc_sq")
+summary = {
+    "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline  (+ separate --pmc passes)",
+    "pass_kernel": pass_name,
+    "pass_launches_working": len(work),
+    "pass_avg_us_working": sum(work) / len(work),
+    "pass_min_us": min(work), "pass_max_us": max(work),
+    "solve_avg_us_working": sum(swork) / max(1, len(swork)),
+    "FETCH_SIZE_KB_per_launch_raw": fetch,
+    "WRITE_SIZE_KB_per_launch_raw": write,
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read on gfx950 -> doubled;
+    # WRITE_SIZE is exact for 16 B/lane stores.  The pass's reads are mostly 16-B gathers and LDS-DMA rows (not a
+    # calibrated pattern) and the whole working set is Infinity-Cache resident, so this is fabric traffic, not DRAM.
+    "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0 if fetch is not None and write is not None else None,
+    "l2": {c: work_mean(l2, "k_gicp_pass", c) for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum")},
+    "sq": {c: work_mean(sq, "k_gicp_pass", c) for c in ("SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD")},
+}
+json.dump(summary, open(os.path.join(DST, "r01_pass_hbm_traffic.json"), "w"), indent=1)
+bench = [l for l in open(os.path.join(SRC, "bench_trace.log")) if l.startswith("{")]
+if bench:
+    open(os.path.join(DST, "r01_bench_under_rocprof.json"), "w").write(bench[-1])
+print(json.dumps(summary, indent=1))
