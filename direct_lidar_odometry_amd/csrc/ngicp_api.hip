@@ -151,7 +151,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
-  DevBuf dbg;
+  DevBuf dbg, sched, n_sched_dev;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
@@ -486,6 +486,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   const int groups_per_block = 256 / lanes;
   (void)groups_per_block;
   lanes = 2;  // the staged kernel is built for 32-query batches (2 lanes per query)
+  if (S.n_batches > kMaxItems) throw ArgError{NGICP_ERR_ARG, "source cloud has too many query batches"};
   int nblocks = pick_blocks((size_t)S.n_batches, 4, h->max_blocks);
   h->partials.ensure((size_t)kNumSlots * h->max_blocks * sizeof(double));
   h->state.ensure(sizeof(LmState));
@@ -497,6 +498,12 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.qpts = S.qpts.as<float4>();
   a.batches = S.batches.as<int2>();
   a.batch_boxes = S.batch_boxes.as<float>();
+  h->sched.ensure((size_t)kMaxItems * sizeof(int4));
+  h->n_sched_dev.ensure(sizeof(int));
+  hipLaunchKernelGGL(k_sched_identity, dim3((unsigned)((S.n_batches + 255) / 256)), dim3(256), 0, h->stream, S.batches.as<int2>(), S.n_batches, h->sched.as<int4>(),
+                     h->n_sched_dev.as<int>());
+  a.sched = h->sched.as<int4>();
+  a.n_sched = h->n_sched_dev.as<int>();
   a.n_batches = S.n_batches;
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
   a.n_src = (int)n;

@@ -10,7 +10,7 @@
 // valid because a clamped point is never closer than its border cell's inner face.
 //
 // The build is a deterministic counting sort: histogram (int atomics) -> exclusive scan ->
-// scatter (int atomics; order inside a cell arbitrary) -> rank-by-original-index inside each
+// scatter (int atomics; order inside a cell arbitrary) -> rank by (x, original index) inside each
 // cell.  The final order is therefore a pure function of the input (bitwise reproducible).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -233,7 +233,9 @@ __global__ void __launch_bounds__(256) k_cell_scatter(const float4* __restrict__
   }
 }
 
-// make the order inside each cell deterministic: rank by original index
+// make the order inside each cell deterministic AND useful: rank by (x, original index).  Cells of a row are
+// ascending in x, so every (y,z) row of the cell-sorted cloud ends up fully sorted by x: the candidates of a row
+// within |x - qx| <= r are one contiguous sub-range that bisection finds
 __global__ void __launch_bounds__(256) k_cell_rank(const float4* __restrict__ tmp, int n, Grid g, const int* __restrict__ cell_start, float4* __restrict__ sorted,
                                                     int* __restrict__ perm) {
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
@@ -244,7 +246,10 @@ __global__ void __launch_bounds__(256) k_cell_rank(const float4* __restrict__ tm
     int s = cell_start[c], e = cell_start[c + 1];
     int my = __float_as_int(me.w);
     int rank = 0;
-    for (int q = s; q < e; ++q) rank += (__float_as_int(tmp[q].w) < my);
+    for (int q = s; q < e; ++q) {
+      const float4 o = tmp[q];
+      rank += (o.x < me.x) || (o.x == me.x && __float_as_int(o.w) < my);
+    }
     sorted[s + rank] = me;
     perm[s + rank] = my;
   }

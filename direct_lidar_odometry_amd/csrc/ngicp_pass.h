@@ -74,6 +74,8 @@ struct PassArgs {
   const float4* qpts;       // source points in Morton-tile query order, w = sorted source position
   const int2* batches;      // tile-aligned query batches {first qpts index, count <= 32}
   const float* batch_boxes; // [n_batches][6] centre + half extents of each batch in the source frame
+  const int4* sched;        // work items {first qpts index, count, batch, 0}
+  const int* n_sched;       // device scalar: number of work items
   int n_batches;
   const double* cov_src;    // [n][6], source sorted order
   int n_src;
@@ -258,11 +260,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 //            Mahalanobis, residual / Jacobian / normal equations.
 // Waves never synchronise with each other inside the loop; the only barrier is the final block-level
 // reduction.  Partials are stored slot-major ([slot][block]) so the solver reads them coalesced.
-constexpr int kStageCap = 768;       // target points per wave stage (12 KB)
+constexpr int kStageCap = 640;       // target points per wave stage (10 KB)
 constexpr int kStageRowsPerLane = 4;
 constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
 constexpr int kStageXs = 20;         // cells per row of the staged region
 constexpr int kStageMaxGrow = 6;
+constexpr int kStageLongRow = 192;   // rows longer than this are not staged
 constexpr int kInnerRows = 100;      // rows of the inner box (query cells +- 1): 10 x 10
 constexpr int kInnerXs = 15;         // its cells per row (16 offsets = 16 lanes)
 
@@ -293,6 +296,99 @@ __device__ __forceinline__ void scan_stage_range(const WaveStage& S, int ps, int
     if (nn_better(d2, base + p2, best, pos)) { best = d2; pos = base + p2; }
     if (nn_better(d3, base + p3, best, pos)) { best = d3; pos = base + p3; }
   }
+}
+
+// A (y,z) row is sorted by x.  Scan the part of the staged row [ps, pe) that can still beat `best`: start at the
+// lower bound of qx - r (bisection), stop once x - qx > r, with r = sqrt(min(best, gate) - gyz) re-evaluated as
+// best improves.  Short rows are scanned whole.
+__device__ __forceinline__ void scan_stage_row_x(const WaveStage& S, int ps, int pe, int base, float qx, float qy, float qz, float gyz, float gate_sq,
+                                                 float& best, int& pos, unsigned int& ncand) {
+  if (pe - ps > 16) {
+    const float lim = fminf(best, gate_sq);
+    if (lim < 1.0e30f) {
+      const float xlo = qx - sqrtf(fmaxf(lim - gyz, 0.f));
+      int lo = ps, hi = pe;  // first index whose x >= xlo
+      while (hi - lo > 4) {
+        const int mid = (lo + hi) >> 1;
+        if (S.pts[mid].x < xlo) lo = mid; else hi = mid;
+      }
+      ps = lo;
+    }
+  }
+  int p = ps;
+  for (; p < pe; p += 4) {
+    const int p1 = min(p + 1, pe - 1), p2 = min(p + 2, pe - 1), p3 = min(p + 3, pe - 1);
+    const float4 a0 = S.pts[p], a1 = S.pts[p1], a2 = S.pts[p2], a3 = S.pts[p3];
+    const float d0 = sqdist(qx, qy, qz, a0), d1 = sqdist(qx, qy, qz, a1), d2 = sqdist(qx, qy, qz, a2), d3 = sqdist(qx, qy, qz, a3);
+    if (nn_better(d0, base + p, best, pos)) { best = d0; pos = base + p; }
+    if (nn_better(d1, base + p1, best, pos)) { best = d1; pos = base + p1; }
+    if (nn_better(d2, base + p2, best, pos)) { best = d2; pos = base + p2; }
+    if (nn_better(d3, base + p3, best, pos)) { best = d3; pos = base + p3; }
+    const float dx = a3.x - qx;  // the largest x of this step
+    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) { p += 4; break; }
+  }
+  ncand += (unsigned)(min(p, pe) - ps);
+}
+// Outward scan of an x-sorted run [s, e) in GLOBAL memory from a starting guess m: walk right, then left, each until the
+// x-gap alone rules the rest out.  Any start is correct (a side only stops once it is past qx AND out of reach); a good
+// start (interpolated from the cell geometry: points of a dense scan line are nearly equidistant in x) makes the cost
+// O(points within reach) with no search at all.  This is what keeps dense scan lines affordable.
+__device__ __forceinline__ void scan_global_outward(const float4* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
+                                                    float& best, int& pos, unsigned int& ncand) {
+  if (e <= s) return;
+  m = min(max(m, s), e - 1);
+  for (int p = m; p < e; p += 8) {  // rightwards, 8 loads in flight
+    float4 c[8];
+    int idx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      idx[j] = min(p + j, e - 1);
+      c[j] = tgt[idx[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = sqdist(qx, qy, qz, c[j]);
+      if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
+    }
+    ncand += 8;
+    const float dx = c[7].x - qx;
+    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
+  }
+  for (int p = m - 1; p >= s; p -= 8) {  // leftwards
+    float4 c[8];
+    int idx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      idx[j] = max(p - j, s);
+      c[j] = tgt[idx[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = sqdist(qx, qy, qz, c[j]);
+      if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
+    }
+    ncand += 8;
+    const float dx = qx - c[7].x;
+    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
+  }
+}
+
+// the same for a run [s, e) of the x-sorted row in global memory
+__device__ __forceinline__ void scan_global_row_x(const float4* __restrict__ tgt, int s, int e, float qx, float qy, float qz, float gyz, float gate_sq,
+                                                  float& best, int& pos, unsigned int& ncand) {
+  int p = s;
+  for (; p < e; p += 4) {
+    const int p1 = min(p + 1, e - 1), p2 = min(p + 2, e - 1), p3 = min(p + 3, e - 1);
+    const float4 a0 = tgt[p], a1 = tgt[p1], a2 = tgt[p2], a3 = tgt[p3];
+    const float d0 = sqdist(qx, qy, qz, a0), d1 = sqdist(qx, qy, qz, a1), d2 = sqdist(qx, qy, qz, a2), d3 = sqdist(qx, qy, qz, a3);
+    if (nn_better(d0, p, best, pos)) { best = d0; pos = p; }
+    if (nn_better(d1, p1, best, pos)) { best = d1; pos = p1; }
+    if (nn_better(d2, p2, best, pos)) { best = d2; pos = p2; }
+    if (nn_better(d3, p3, best, pos)) { best = d3; pos = p3; }
+    const float dx = a3.x - qx;
+    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) { p += 4; break; }
+  }
+  ncand += (unsigned)(min(p, e) - s);
 }
 
 #define NG_STAMP(k)                                                                                   \
@@ -328,50 +424,23 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) Tf[i] = st->xi_f[i];
 
-  double acc[kNumSums];
-#pragma unroll
-  for (int i = 0; i < kNumSums; ++i) acc[i] = 0.0;
+  double wave_total = 0.0;  // lane v (< 29) accumulates slot v of this wave over its batches
   unsigned int ncand = 0, nvalid = 0, nstaged = 0;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % G, grp = lane / G;
   WaveStage& S = stage_all[wave];
   NG_STAMP(0);
-  // XCD-aware work assignment: blocks are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8, each
-  // with its own 4 MB L2), and batches are in Morton order, so XCD x takes the x-th contiguous eighth of the
-  // batch list: a compact part of space whose slice of the target index stays resident in that XCD's L2.
-  // (Speed only: any placement gives the same result.)
-  const int xcd = blockIdx.x & 7, slot = (blockIdx.x >> 3) * 4 + wave, slots = ((gridDim.x + 7 - xcd) >> 3) * 4;
-  const int chunk = (a.n_batches + 7) >> 3;
-  const int chunk_end = min((xcd + 1) * chunk, a.n_batches);
-  for (int batch = xcd * chunk + slot; batch < chunk_end; batch += slots) {
-    const int2 bd = a.batches[batch];
-    const int qbase = bd.x, qcount = bd.y;
+  // Work items come from a static schedule: block b, wave w takes item 4b + w, then strides by the grid.  Static => the
+  // summation order, and with it the result, is reproducible run to run.
+  const int n_items = *a.n_sched;
+  for (int item = blockIdx.x * 4 + wave; item < n_items; item += gridDim.x * 4) {
+    const int4 it = a.sched[item];
+    const int qbase = it.x, qcount = it.y, batch = it.z;
     float mybest = 3.4028234664e38f;
     int mypos = -1;
-    // operands of the FP64 tail that do not depend on the search are requested first, so that their
-    // latency hides behind the search
     const int i = qbase + lane;
     const bool mine = lane < qcount;
-    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j_old = -1;
-    double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
-    if (mine) {
-      sp = a.qpts[i];
-      if (do_err) {
-        j_old = corr_old[i];
-        const double* M = mahal_old + (size_t)i * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) Mold[e] = M[e];
-      }
-      if (do_lin) {
-        const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) ca[e] = CA[e];
-      }
-    }
-    float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mine && j_old >= 0) bp_old = a.tgt[j_old];
     NG_STAMP(1);
 
     if (do_lin && (a.mode & 8)) {  // DEBUG timing build: fake search result
@@ -414,90 +483,121 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       const int iX0 = max(b0x - 1, 0), iY0 = max(b0y - 1, 0), iZ0 = max(b0z - 1, 0);
       const int iX1 = min(b1x + 1, g.nx - 1), iY1 = min(b1y + 1, g.ny - 1), iZ1 = min(b1z + 1, g.nz - 1);
       const int iwy = iY1 - iY0 + 1, irows = iwy * (iZ1 - iZ0 + 1), iXS = iX1 - iX0 + 1;
-      int X0 = 0, Y0 = 0, Z0 = 0, wy = 1, grow = 0;
-      bool staged = false;
+      int X0 = 0, Y0 = 0, Z0 = 0, wy = 1, grow = 0, nlive = 0;
+      bool staged = false, listed = false;
       if (a.stage_grow >= 1 && irows <= kInnerRows && iXS <= kInnerXs) {
-        const int bmax = max(max(b1x - b0x, b1y - b0y), b1z - b0z) + 1;
-        grow = a.stage_grow;
-        for (int attempt = 0; attempt < 3 && grow >= 1 && !staged; ++attempt) {
-          int XS, rows;
-          for (;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
-            X0 = max(b0x - grow, 0);
-            Y0 = max(b0y - grow, 0);
-            Z0 = max(b0z - grow, 0);
-            const int X1 = min(b1x + grow, g.nx - 1), Y1 = min(b1y + grow, g.ny - 1), Z1 = min(b1z + grow, g.nz - 1);
-            XS = X1 - X0 + 1;
-            wy = Y1 - Y0 + 1;
-            rows = wy * (Z1 - Z0 + 1);
-            if ((rows <= kStageRows && XS <= kStageXs) || grow == 1) break;
-          }
-          if (rows > kStageRows || XS > kStageXs) break;
-          // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target
-          int rb[kStageRowsPerLane], rs[kStageRowsPerLane], rn[kStageRowsPerLane], ro[kStageRowsPerLane];
+        int XS, rows;
+        for (grow = a.stage_grow;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
+          X0 = max(b0x - grow, 0);
+          Y0 = max(b0y - grow, 0);
+          Z0 = max(b0z - grow, 0);
+          const int X1 = min(b1x + grow, g.nx - 1), Y1 = min(b1y + grow, g.ny - 1), Z1 = min(b1z + grow, g.nz - 1);
+          XS = X1 - X0 + 1;
+          wy = Y1 - Y0 + 1;
+          rows = wy * (Z1 - Z0 + 1);
+          if ((rows <= kStageRows && XS <= kStageXs) || grow == 1) break;
+        }
+        if (rows <= kStageRows && XS <= kStageXs) {
+          // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target, and the
+          // row's ring distance from the batch box (rows are staged and listed nearest ring first)
+          int rb[kStageRowsPerLane], rs[kStageRowsPerLane], rn[kStageRowsPerLane], ro[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane];
+          bool rst[kStageRowsPerLane];
 #pragma unroll
           for (int k = 0; k < kStageRowsPerLane; ++k) {
             const int r = lane + 64 * k;
             const bool has = r < rows;
-            rb[k] = has ? ((Z0 + r / wy) * g.ny + (Y0 + r % wy)) * g.nx + X0 : 0;
+            const int ry = Y0 + r % wy, rz = Z0 + r / wy;
+            rb[k] = has ? (rz * g.ny + ry) * g.nx + X0 : 0;
             const int sv = has ? a.tgt_cell_start[rb[k]] : 0, ev = has ? a.tgt_cell_start[rb[k] + XS] : 0;
             rs[k] = sv;
             rn[k] = ev - sv;
+            rho[k] = max(max(b0y - ry, ry - b1y), max(max(b0z - rz, rz - b1z), 0));
+            ryz[k] = ry | (rz << 16);
+            ro[k] = 0;
+            rst[k] = false;
           }
-          wave_lds_sync();  // the previous batch's (or attempt's) readers are done with the slice
+          wave_lds_sync();  // the previous batch's readers are done with the slice
           if (lane == 0) S.alloc = 0;
           wave_lds_sync();
-          // LDS space for each non-empty row from a bump allocator (placement order is irrelevant: positions are
-          // mapped back to global sorted positions, and candidates are ranked by a total order)
+          // ring by ring: list the non-empty rows and give them LDS space until the slice is full (rows that do
+          // not fit stay in global memory; they are the far ones and few of them survive pruning)
+          for (int lev = 0; lev <= grow; ++lev) {
 #pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k) ro[k] = rn[k] > 0 ? atomicAdd(&S.alloc, rn[k]) : 0;
-          wave_lds_sync();
-          const int total = S.alloc;
-          if (total > kStageCap) {
-            if (grow == 1) break;
-            // surface-like data: the point count scales with the region's face area
-            const float ratio = sqrtf(0.8f * (float)kStageCap / (float)total);
-            const int side = (int)((float)(bmax + 2 * grow) * ratio);
-            grow = max(1, min(grow - 1, (side - bmax) / 2));
-            continue;
-          }
-          staged = true;
-          int nlive = 0;
-#pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k) {
-            const int r = lane + 64 * k;
-            const unsigned long long live = __ballot(rn[k] > 0);
-            if (rn[k] > 0) {
-              const int li = nlive + __popcll(live & ((1ull << lane) - 1ull));
-              S.live[li] = make_int4((Y0 + r % wy) | ((Z0 + r / wy) << 16), ro[k] | ((ro[k] + rn[k]) << 16), rs[k] - ro[k], 0);
-              S.row_live[r] = (unsigned short)li;
-            } else if (r < rows) {
-              S.row_live[r] = 0xffffu;
+            for (int k = 0; k < kStageRowsPerLane; ++k) {
+              const bool on = rn[k] > 0 && rho[k] == lev;
+              const unsigned long long m = __ballot(on);
+              if (on) {
+                const int li = nlive + __popcll(m & ((1ull << lane) - 1ull));
+                // long rows (a dense scan line along x) stay in global memory and are read through x-windows; a row
+                // that would overflow the slice is skipped without consuming space, so shorter ones behind it still fit
+                int o = 0;
+                bool fits = rn[k] <= kStageLongRow;
+                if (fits) {
+                  o = atomicAdd(&S.alloc, rn[k]);
+                  fits = o + rn[k] <= kStageCap;
+                  if (!fits) atomicSub(&S.alloc, rn[k]);
+                }
+                rst[k] = fits;
+                ro[k] = o;
+                // record: {y | z << 16, staged ? (lds_begin | lds_end << 16) : -count, staged ? global - lds : global_begin, 0}
+                S.live[li] = rst[k] ? make_int4(ryz[k], o | ((o + rn[k]) << 16), rs[k] - o, 0) : make_int4(ryz[k], -rn[k], rs[k], 0);
+                S.row_live[lane + 64 * k] = (unsigned short)li;
+              }
+              nlive += __popcll(m);
             }
-            nlive += __popcll(live);
           }
-          // every NON-EMPTY row is one contiguous run -> LDS-DMA pieces, all in flight together; row parameters
-          // travel by v_readlane (no LDS or memory round trip in the issue loop).  Rows of the inner box also
-          // fetch their per-cell offsets (lanes along x); the stores are deferred so that the loads overlap.
-          int pend_i[4], pend_v[4], pend_o[4];
-          int npend = 0;
+#pragma unroll
+          for (int k = 0; k < kStageRowsPerLane; ++k)
+            if (rn[k] == 0 && lane + 64 * k < rows) S.row_live[lane + 64 * k] = 0xffffu;
+          staged = true;
+          listed = true;
+          // staged rows are contiguous runs of the cell-sorted target.  Short rows (the common case in sparse regions)
+          // are copied by their owner lane, all lanes in parallel, 8 loads in flight per row; longer rows go by LDS-DMA,
+          // one wave-wide piece per 64 points (row parameters travel by v_readlane).
 #pragma unroll
           for (int k = 0; k < kStageRowsPerLane; ++k) {
-            unsigned long long live = __ballot(rn[k] > 0);
+            const bool shortrow = rst[k] && rn[k] > 0 && rn[k] <= 8;
+#pragma unroll
+            for (int j0 = 0; j0 < 8; j0 += 4) {
+              float4 v[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = (shortrow && j0 + j < rn[k]) ? a.tgt[rs[k] + j0 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (shortrow && j0 + j < rn[k]) S.pts[ro[k] + j0 + j] = v[j];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < kStageRowsPerLane; ++k) {
+            unsigned long long live = __ballot(rst[k] && rn[k] > 8);
             while (live) {
               const int rl = __builtin_ctzll(live);
               live &= live - 1;
               const int cnt = __builtin_amdgcn_readlane(rn[k], rl), src0 = __builtin_amdgcn_readlane(rs[k], rl);
-              const int dst0 = __builtin_amdgcn_readlane(ro[k], rl), base = __builtin_amdgcn_readlane(rb[k], rl);
+              const int dst0 = __builtin_amdgcn_readlane(ro[k], rl);
               for (int j0 = 0; j0 < cnt; j0 += 64) {
                 if (j0 + lane < cnt)
                   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.tgt + src0 + j0 + lane),
                                                    (void __attribute__((address_space(3)))*)(S.pts + dst0 + j0), 16, 0, 0);
               }
-              const int r = rl + 64 * k;
-              const int y = Y0 + r % wy, z = Z0 + r / wy;
+            }
+          }
+          // per-cell offsets of the staged rows of the inner box (lanes along x); the stores are deferred so that the
+          // loads of four rows overlap
+          int pend_i[4], pend_v[4], pend_o[4];
+          int npend = 0;
+#pragma unroll
+          for (int k = 0; k < kStageRowsPerLane; ++k) {
+            unsigned long long live = __ballot(rst[k] && rn[k] > 0 && rho[k] <= 1);
+            while (live) {
+              const int rl = __builtin_ctzll(live);
+              live &= live - 1;
+              const int yz = __builtin_amdgcn_readlane(ryz[k], rl);
+              const int y = yz & 0xffff, z = yz >> 16;
               if (y >= iY0 && y <= iY1 && z >= iZ0 && z <= iZ1) {
+                const int base = __builtin_amdgcn_readlane(rb[k], rl);
                 pend_i[npend] = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
-                pend_o[npend] = dst0 - src0;
+                pend_o[npend] = __builtin_amdgcn_readlane(ro[k], rl) - __builtin_amdgcn_readlane(rs[k], rl);
                 pend_v[npend] = (lane <= iXS) ? a.tgt_cell_start[base + (iX0 - X0) + lane] : 0;
                 if (++npend == 4) {
 #pragma unroll
@@ -511,7 +611,6 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 #pragma unroll
           for (int u = 0; u < 4; ++u)
             if (u < npend && lane <= iXS) S.cell_off[pend_i[u] + lane] = (unsigned short)(pend_v[u] + pend_o[u]);
-          if (lane == 0) S.alloc = nlive;  // from here on: the number of live rows
           __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the DMA pieces have landed
           wave_lds_sync();
         }
@@ -520,7 +619,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       if (a.dbg_stamps && lane == 0) {
         unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
         d[10] = (unsigned long long)(staged ? grow : 0);
-        d[11] = (unsigned long long)(staged ? S.alloc : 0);
+        d[11] = (unsigned long long)nlive;
         d[12] = (unsigned long long)qcount;
         d[13] = (unsigned long long)((b1x - b0x + 1) | ((b1y - b0y + 1) << 8) | ((b1z - b0z + 1) << 16));
       }
@@ -528,31 +627,55 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         int rdone = 1;  // rings 0..rdone have been searched exhaustively
         // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
         // simply takes the global path
-        const bool in_box = staged && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
-        if (in_box) {
+        const bool in_box = listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
+        if (in_box && staged) {
           if (sub == 0) ++nstaged;
           // ---- rings 0..1 out of LDS: lane `sub` takes rows sub, sub + G, ... of the 3 x 3 (y,z) window ----
           const int c0 = max(cx - 1, 0) - iX0, c1 = min(cx + 1, g.nx - 1) - iX0 + 1;
+          // rows of the 3 x 3 window, nearest first (own row, then the four edge neighbours, then the corners), so that
+          // the later rows are pruned by their (y,z) gap against a best that is already tight
 #pragma unroll
           for (int k = 0; k < (9 + G - 1) / G; ++k) {
-            const int tt = sub + k * G;
+            const int order = sub + k * G;                          // 0..8 in visiting order
+            const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
             const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-            if (tt < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+              float gy = 0.f, gz = 0.f;
+              if (y > cy) gy = (g.oy + (float)y * g.h) - qy; else if (y < cy) gy = qy - (g.oy + (float)(y + 1) * g.h);
+              if (z > cz) gz = (g.oz + (float)z * g.h) - qz; else if (z < cz) gz = qz - (g.oz + (float)(z + 1) * g.h);
+              gy = fmaxf(gy - g.slack, 0.f);
+              gz = fmaxf(gz - g.slack, 0.f);
+              const float gyz = gy * gy + gz * gz;
               const int li = S.row_live[(z - Z0) * wy + (y - Y0)];
-              if (li != 0xffff) {  // empty rows carry no cell offsets
-                const int ci = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
-                scan_stage_range(S, S.cell_off[ci + c0], S.cell_off[ci + c1], S.live[li].z, qx, qy, qz, best, pos, ncand);
+              if (li != 0xffff && gyz <= fminf(best, a.gate_sq_f)) {  // empty rows carry no cell offsets
+                const int4 rec = S.live[li];
+                if (rec.y >= 0) {
+                  const int ci = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
+                  scan_stage_range(S, S.cell_off[ci + c0], S.cell_off[ci + c1], rec.z, qx, qy, qz, best, pos, ncand);
+                } else {  // a row that was not staged (dense scan line): its three cells from global memory
+                  const int rowb = (z * g.ny + y) * g.nx;
+                  const int s0 = a.tgt_cell_start[rowb + c0 + iX0], e0 = a.tgt_cell_start[rowb + c1 + iX0];
+                  // start where qx would sit if the window's points were equidistant in x
+                  const float xl = g.ox + (float)(c0 + iX0) * g.h, frac = (qx - xl) / ((float)(c1 - c0) * g.h);
+                  scan_global_outward(a.tgt, s0, e0, s0 + (int)(fminf(fmaxf(frac, 0.f), 1.f) * (float)(e0 - s0)), qx, qy, qz, gyz, a.gate_sq_f, best, pos, ncand);
+                }
               }
             }
+            if (k == 0 && G > 1) group_min<G>(best, pos);  // both lanes continue from the better of the two nearest rows
           }
           if (G > 1) group_min<G>(best, pos);
-          NG_STAMP(4);
-          // ---- rings 2..grow: the staged rows that can still hold a closer point ----
+        } else {
+          nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
+        }
+        NG_STAMP(4);
+        const unsigned int dbg_c1 = ncand;
+        unsigned int dbg_rows = 0, dbg_urows = 0;
+        if (in_box) {
+          // ---- rings 2..grow: the listed rows (nearest ring first) that can still hold a closer point ----
           if (grow >= 2) {
             const float bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
             if (!(best <= bound1 || bound1 >= a.gate_sq_f)) {
-              const int nl = S.alloc;
-              for (int li = sub; li < nl; li += G) {
+              for (int li = sub; li < nlive; li += G) {
                 const int4 rec = S.live[li];
                 const int ry = rec.x & 0xffff, rz = rec.x >> 16;
                 // lower bound of the distance from q to anything in row (ry, rz): the (y,z) gap to its cells
@@ -561,17 +684,34 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
                 if (rz > cz) gz = (g.oz + (float)rz * g.h) - qz; else if (rz < cz) gz = qz - (g.oz + (float)(rz + 1) * g.h);
                 gy = fmaxf(gy - g.slack, 0.f);
                 gz = fmaxf(gz - g.slack, 0.f);
-                if (gy * gy + gz * gz > best) continue;
-                scan_stage_range(S, rec.y & 0xffff, (int)((unsigned)rec.y >> 16), rec.z, qx, qy, qz, best, pos, ncand);
+                const float gyz = gy * gy + gz * gz;
+                if (gyz > fminf(best, a.gate_sq_f)) continue;
+                ++dbg_rows;
+                if (rec.y < 0) ++dbg_urows;
+                if (rec.y >= 0) {
+                  scan_stage_row_x(S, rec.y & 0xffff, (int)((unsigned)rec.y >> 16), rec.z, qx, qy, qz, gyz, a.gate_sq_f, best, pos, ncand);
+                } else {
+                  // the row did not fit the slice (a dense scan line): outward from where qx sits among the three centre
+                  // cells (interpolated), over the whole region row
+                  const int rowb = (rz * g.ny + ry) * g.nx;
+                  const int ca = max(cx - 1, 0), cb = min(cx + 1, g.nx - 1) + 1;
+                  const int s0 = a.tgt_cell_start[rowb + ca], e0 = a.tgt_cell_start[rowb + cb];
+                  const float xl = g.ox + (float)ca * g.h, frac = (qx - xl) / ((float)(cb - ca) * g.h);
+                  scan_global_outward(a.tgt, rec.z, rec.z - rec.y, s0 + (int)(fminf(fmaxf(frac, 0.f), 1.f) * (float)(e0 - s0)), qx, qy, qz, gyz, a.gate_sq_f, best,
+                                      pos, ncand);
+                }
               }
               if (G > 1) group_min<G>(best, pos);
               rdone = grow;
             }
           }
-        } else {
-          nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
         }
         NG_STAMP(5);
+        if (a.dbg_stamps) {
+          unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
+          atomicMax(&d[14], (unsigned long long)(ncand - dbg_c1) | ((unsigned long long)dbg_rows << 32) | ((unsigned long long)dbg_urows << 48));
+          atomicMax(&d[15], (unsigned long long)dbg_c1);
+        }
         nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, rdone, best, pos, ncand);
       }
       NG_STAMP(6);
@@ -580,7 +720,30 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       mybest = __shfl(best, src_lane);
       mypos = __shfl(pos, src_lane);
     }
-    // ---- tail: one query per lane ----
+    // ---- tail: one query per lane.  Its operands are fetched only now: holding them across the search costs ~40
+    //      registers (and with them a resident wave per SIMD), more than the one round trip it would hide ----
+    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j_old = -1;
+    double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
+    float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+      sp = a.qpts[i];
+      if (do_err) {
+        j_old = corr_old[i];
+        const double* M = mahal_old + (size_t)i * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) Mold[e] = M[e];
+      }
+      if (do_lin) {
+        const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ca[e] = CA[e];
+      }
+      if (j_old >= 0) bp_old = a.tgt[j_old];
+    }
+    double acc[kNumSums];
+#pragma unroll
+    for (int v = 0; v < kNumSums; ++v) acc[v] = 0.0;
     if ((a.mode & 16) && mine) {  // DEBUG timing build: skip the FP64 tail
       corr_new[i] = mypos;
       acc[27] += (double)mybest;
@@ -654,33 +817,40 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         }
       }
     }
+    // ---- R0: per-batch reduction through LDS (the stage slice is free now): lanes 0..31 hold the tail's sums;
+    //      lane l writes row l of a [32][30] tile, lane v then adds column v in fixed order (deterministic).  A butterfly
+    //      of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips.
+    {
+      wave_lds_sync();
+      double* red = reinterpret_cast<double*>(S.pts);  // [32][30] doubles
+      if (lane < 32) {
+#pragma unroll
+        for (int v = 0; v < kNumSums; ++v) red[lane * 30 + v] = acc[v];
+      }
+      wave_lds_sync();
+      if (lane < kNumSums) {
+        double out = 0.0;
+        for (int l = 0; l < 32; ++l) out += red[l * 30 + lane];
+        wave_total += out;
+      }
+    }
   }
 
   NG_STAMP(7);
-  // ---- R0: per-wave reduction through LDS (the stage slice is free now): lanes 0..31 hold the tail's sums ----
-  //      lane l writes row l of a [32][30] tile, lane v then adds column v in fixed order (deterministic);
-  //      a butterfly of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips
   {
+    // counters: [3][64] through LDS, lanes 29..31 add their column
     wave_lds_sync();
-    double* red = reinterpret_cast<double*>(S.pts);                       // [32][30] doubles
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(red + 32 * 30);  // [3][64] counters
-    if (lane < 32) {
-#pragma unroll
-      for (int v = 0; v < kNumSums; ++v) red[lane * 30 + v] = acc[v];
-    }
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(S.pts);
     cnt[lane] = ncand;
     cnt[64 + lane] = nvalid;
     cnt[128 + lane] = nstaged;
     wave_lds_sync();
-    double out = 0.0;
-    if (lane < kNumSums) {
-      for (int l = 0; l < 32; ++l) out += red[l * 30 + lane];
-    } else if (lane < kNumSlots) {
+    if (lane >= kNumSums && lane < kNumSlots) {
       unsigned int sum = 0;
       for (int l = 0; l < 64; ++l) sum += cnt[(lane - kNumSums) * 64 + l];
-      out = (double)sum;
+      wave_total = (double)sum;
     }
-    if (lane < kNumSlots) lds[wave][lane] = out;
+    if (lane < kNumSlots) lds[wave][lane] = wave_total;
   }
   NG_STAMP(8);
   __syncthreads();
@@ -694,6 +864,15 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 
 // Upper-triangular packing used by the pass: index of (r,c), r <= c, in the 21-vector
 __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+// --- work schedule -------------------------------------------------------------------------------------------
+constexpr int kMaxItems = 16384;
+// identity schedule: one item per batch, in batch (Morton) order
+__global__ void __launch_bounds__(256) k_sched_identity(const int2* __restrict__ batches, int n_batches, int4* __restrict__ sched, int* __restrict__ n_sched) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_batches) sched[i] = make_int4(batches[i].x, batches[i].y, i, 0);
+  if (i == 0) *n_sched = n_batches;
+}
 
 // --- the solver ----------------------------------------------------------------------------------
 constexpr int kSolveThreads = 256;  // 4 waves: keeps the full VGPR budget for the serial lane

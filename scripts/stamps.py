@@ -30,5 +30,7 @@ order = np.argsort(-life)[:12]
 print("slowest waves: life | prologue, cells, stage, ring1, far, shells, tail, reduce | grow nlive qcount box")
 for w in order:
     d = [a[w, k] - a[w, k - 1] if a[w, k] > 0 and a[w, k-1] > 0 else -1 for k in range(1, 9)]
-    print(int(life[w]), [int(x) for x in d], int(g[w]), int(nl[w]), int(qc[w]), (int(bb[w]) & 255, (int(bb[w]) >> 8) & 255, (int(bb[w]) >> 16) & 255))
+    x14 = int(a[w, 14]); x15 = int(a[w, 15])
+    print(int(life[w]), [int(x) for x in d], int(g[w]), int(nl[w]), int(qc[w]), (int(bb[w]) & 255, (int(bb[w]) >> 8) & 255, (int(bb[w]) >> 16) & 255),
+          "max-lane: ring1 cand", x15, "far cand", x14 & 0xffffffff, "far rows", (x14 >> 32) & 0xffff, "unstaged", x14 >> 48)
 print("sum of wave lifetimes (to reduce-done):", life.sum(), " / 2048 slots =", life.sum() / 2048)
