@@ -1014,10 +1014,12 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
 __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ double wsum[kSolveThreads / 64][kPartialStride];
   __shared__ double sums[kPartialStride];
+  __shared__ double red_tile[kSolveThreads / 64][64 * 33];
   LmState* st = a.st;
   if (a.mode == 0 && st->hot.done) return;
 
-  // ---- deterministic reduction of the block partials; all 31 loads of a step are in flight together ----
+  // ---- deterministic reduction of the block partials: all loads of a step in flight together, then a transpose
+  //      through LDS (lane v adds column v in fixed order) instead of a butterfly of 64-bit LDS-crossbar shuffles ----
   double acc[kNumSlots];
 #pragma unroll
   for (int v = 0; v < kNumSlots; ++v) acc[v] = 0.0;
@@ -1026,10 +1028,23 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
     for (int v = 0; v < kNumSlots; ++v) acc[v] += a.partials[(size_t)v * a.pitch + b];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    double* tile = red_tile[wave];  // [64][33]
 #pragma unroll
-  for (int v = 0; v < kNumSlots; ++v) {
-    const double s = wave_sum(acc[v]);
-    if (lane == 0) wsum[wave][v] = s;
+    for (int v = 0; v < kNumSlots; ++v) tile[lane * 33 + v] = acc[v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < kNumSlots) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four interleaved chains: (l mod 4) fixed order
+      for (int l = 0; l < 64; l += 4) {
+        s0 += tile[(l + 0) * 33 + lane];
+        s1 += tile[(l + 1) * 33 + lane];
+        s2 += tile[(l + 2) * 33 + lane];
+        s3 += tile[(l + 3) * 33 + lane];
+      }
+      wsum[wave][lane] = (s0 + s1) + (s2 + s3);
+    }
   }
   __syncthreads();
   if (threadIdx.x < kPartialStride) {
