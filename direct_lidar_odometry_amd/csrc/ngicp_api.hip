@@ -143,7 +143,6 @@ struct ngicp {
   int lanes_per_query = 0;  // 0 = auto
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
-  int max_blocks = 1024;    // pass-kernel grid cap: 4 blocks per CU; waves stride over the work items
   bool profiling = false;
 
   Slot src, tgt;
@@ -151,7 +150,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
-  DevBuf dbg, sched, n_sched_dev;
+  DevBuf dbg, grp_order, grp_cost;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
@@ -486,9 +485,10 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   const int groups_per_block = 256 / lanes;
   (void)groups_per_block;
   lanes = 2;  // the staged kernel is built for 32-query batches (2 lanes per query)
-  if (S.n_batches > kMaxItems) throw ArgError{NGICP_ERR_ARG, "source cloud has too many query batches"};
-  int nblocks = pick_blocks((size_t)S.n_batches, 4, h->max_blocks);
-  h->partials.ensure((size_t)kNumSlots * h->max_blocks * sizeof(double));
+  const int nblocks = std::max(1, (S.n_batches + 3) / 4);  // one block per group of four batches
+  h->partials.ensure((size_t)kNumSlots * nblocks * sizeof(double));
+  h->grp_order.ensure((size_t)nblocks * sizeof(int));
+  h->grp_cost.ensure((size_t)nblocks * sizeof(int));
   h->state.ensure(sizeof(LmState));
   const int max_rows = std::max(1, h->p.max_iter) * std::max(1, h->p.lm_max_iter) + 1;
   h->trace.ensure((size_t)max_rows * kTraceCols * sizeof(double));
@@ -498,12 +498,8 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.qpts = S.qpts.as<float4>();
   a.batches = S.batches.as<int2>();
   a.batch_boxes = S.batch_boxes.as<float>();
-  h->sched.ensure((size_t)kMaxItems * sizeof(int4));
-  h->n_sched_dev.ensure(sizeof(int));
-  hipLaunchKernelGGL(k_sched_identity, dim3((unsigned)((S.n_batches + 255) / 256)), dim3(256), 0, h->stream, S.batches.as<int2>(), S.n_batches, h->sched.as<int4>(),
-                     h->n_sched_dev.as<int>());
-  a.sched = h->sched.as<int4>();
-  a.n_sched = h->n_sched_dev.as<int>();
+  a.grp_order = h->grp_order.as<int>();
+  a.grp_cost = h->grp_cost.as<int>();
   a.n_batches = S.n_batches;
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
   a.n_src = (int)n;
@@ -523,7 +519,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   }
   a.st = h->state.as<LmState>();
   a.partials = h->partials.as<double>();
-  a.partial_pitch = h->max_blocks;
+  a.partial_pitch = nblocks;
   a.mode = 3;
   a.dbg_stamps = nullptr;
   {
@@ -543,7 +539,9 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.cfg.lm_init_lambda_factor = h->p.lm_init_lambda_factor;
   s.partials = a.partials;
   s.nblocks = nblocks;
-  s.pitch = h->max_blocks;
+  s.pitch = nblocks;
+  s.grp_order = h->grp_order.as<int>();
+  s.grp_cost = h->grp_cost.as<int>();
   s.trace = h->trace.as<double>();
   s.max_trace_rows = max_rows;
   s.mode = 0;
@@ -807,7 +805,6 @@ int ngicp_create(int device, ngicp_t** out) {
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_LANES")) h->lanes_per_query = std::atoi(s);
     if (const char* s = std::getenv("NGICP_STAGE_GROW")) h->stage_grow = std::max(0, std::min(kStageMaxGrow, std::atoi(s)));
-    if (const char* s = std::getenv("NGICP_MAX_BLOCKS")) h->max_blocks = std::max(1, std::min(65536, std::atoi(s)));
     *out = h.release();
     return NGICP_OK;
   } catch (const HipError& e) {
@@ -1172,6 +1169,7 @@ int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* stream_or_nul
     c.sa.partials = sums32_dev;  // one pre-reduced vector
     c.sa.nblocks = 1;
     c.sa.pitch = 1;
+    c.sa.grp_order = nullptr;  // the vector is one pre-reduced column, not per-group partials
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
     LmState* dst = h->state.as<LmState>();
     HIP_TRY(hipMemcpyAsync(&h->h_poll[0], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, s));

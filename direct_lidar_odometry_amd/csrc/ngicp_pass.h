@@ -68,14 +68,15 @@ struct LmState {
   LmHot hot;
   float xi_f[12];  // float(xi): rows of [R|t], the matrix used for the NN query (impl/nano_gicp_impl.hpp:178)
   double final_hessian[36];
+  int order_valid;  // the solver has published a group order (heaviest first) for the next pass
 };
 
 struct PassArgs {
   const float4* qpts;       // source points in Morton-tile query order, w = sorted source position
   const int2* batches;      // tile-aligned query batches {first qpts index, count <= 32}
   const float* batch_boxes; // [n_batches][6] centre + half extents of each batch in the source frame
-  const int4* sched;        // work items {first qpts index, count, batch, 0}
-  const int* n_sched;       // device scalar: number of work items
+  const int* grp_order;     // [n_groups] launch order of the groups (a block takes group grp_order[blockIdx.x]); valid when st->order_valid
+  int* grp_cost;            // [n_groups] measured duration of each group's block in the last pass (shader clocks >> 4), or null
   int n_batches;
   const double* cov_src;    // [n][6], source sorted order
   int n_src;
@@ -89,7 +90,7 @@ struct PassArgs {
   float gate_sq_f;          // float upper bound of gate_sq for ring termination
   LmState* st;
   double* partials;         // [kNumSlots][partial_pitch], slot-major
-  int partial_pitch;        // >= gridDim.x
+  int partial_pitch;        // >= number of groups
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
   int stage_grow;           // rings served from the LDS stage (0: none)
   unsigned long long* dbg_stamps;  // diagnostic build only: [wave][16] s_memtime stamps, or null
@@ -431,12 +432,15 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   const int sub = lane % G, grp = lane / G;
   WaveStage& S = stage_all[wave];
   NG_STAMP(0);
-  // Work items come from a static schedule: block b, wave w takes item 4b + w, then strides by the grid.  Static => the
-  // summation order, and with it the result, is reproducible run to run.
-  const int n_items = *a.n_sched;
-  for (int item = blockIdx.x * 4 + wave; item < n_items; item += gridDim.x * 4) {
-    const int4 it = a.sched[item];
-    const int qbase = it.x, qcount = it.y, batch = it.z;
+  // A block owns one GROUP of four consecutive batches (one per wave); its partial sums are stored under the group's
+  // index, so the result does not depend on the order in which groups are launched.  That order is the solver's business:
+  // it sorts the groups by the duration measured in the previous pass, heaviest first (the grid is ~1.7 waves of blocks
+  // deep, and the slowest groups take 2-3x the median: started late they would set the kernel's length).
+  const int group = (a.grp_order && st->order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
+  const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int item = group * 4 + wave; item < a.n_batches; item = a.n_batches) {
+    const int2 it = a.batches[item];
+    const int qbase = it.x, qcount = it.y, batch = item;
     float mybest = 3.4028234664e38f;
     int mypos = -1;
     const int i = qbase + lane;
@@ -857,22 +861,14 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   NG_STAMP(9);
   if (threadIdx.x < kNumSlots) {
     const int v = threadIdx.x;
-    a.partials[(size_t)v * a.partial_pitch + blockIdx.x] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
+    a.partials[(size_t)v * a.partial_pitch + group] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
   }
+  if (a.grp_cost && threadIdx.x == 0) a.grp_cost[group] = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
 }
 #undef NG_STAMP
 
 // Upper-triangular packing used by the pass: index of (r,c), r <= c, in the 21-vector
 __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
-
-// --- work schedule -------------------------------------------------------------------------------------------
-constexpr int kMaxItems = 16384;
-// identity schedule: one item per batch, in batch (Morton) order
-__global__ void __launch_bounds__(256) k_sched_identity(const int2* __restrict__ batches, int n_batches, int4* __restrict__ sched, int* __restrict__ n_sched) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_batches) sched[i] = make_int4(batches[i].x, batches[i].y, i, 0);
-  if (i == 0) *n_sched = n_batches;
-}
 
 // --- the solver ----------------------------------------------------------------------------------
 constexpr int kSolveThreads = 256;  // 4 waves: keeps the full VGPR budget for the serial lane
@@ -887,6 +883,8 @@ struct SolveArgs {
   int max_trace_rows;
   int mode;                // 0: LM/GN state machine; 1: reduce -> H/b/y0 (linearize hook); 2: reduce -> y0 = yi (error hook); 3: reduce only
   double* sums_out;        // optional [kPartialStride] reduced sums (29 sums + 2 counters + 1 pad)
+  int* grp_order;          // [nblocks] out: groups sorted by measured cost, heaviest first (mode 0 only), or null
+  const int* grp_cost;     // [nblocks] in: duration of each group's block in the pass just finished
 };
 
 __device__ __forceinline__ bool is_converged_dev(const Pose& d, double rot_eps, double trans_eps) {  // impl/lsq_registration_impl.hpp:118-127
@@ -1015,6 +1013,7 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ double wsum[kSolveThreads / 64][kPartialStride];
   __shared__ double sums[kPartialStride];
   __shared__ double red_tile[kSolveThreads / 64][64 * 33];
+  __shared__ int ord_cnt[16], ord_pos[16], ord_max;
   LmState* st = a.st;
   if (a.mode == 0 && st->hot.done) return;
 
@@ -1054,6 +1053,36 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __syncthreads();
   if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
   if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
+  if (a.mode == 0 && a.grp_order && wave == 1) {
+    // ---- launch order of the next pass, built by wave 1 while lane 0 runs the state machine: 16 cost classes
+    //      relative to the slowest group, heaviest class first.  The order inside a class is whatever the LDS
+    //      atomics make it: the pass's results do not depend on the launch order. ----
+    auto wsync = [] {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if (lane < 16) ord_cnt[lane] = 0;
+    if (lane == 0) ord_max = 1;
+    wsync();
+    int mx = 0;
+    for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, a.grp_cost[gi]);
+    atomicMax(&ord_max, mx);
+    wsync();
+    const long long M = (long long)ord_max + 1;
+    for (int gi = lane; gi < a.nblocks; gi += 64) atomicAdd(&ord_cnt[15 - (int)(((long long)a.grp_cost[gi] * 16) / M)], 1);
+    wsync();
+    if (lane == 0) {
+      int run = 0;
+      for (int c = 0; c < 16; ++c) {
+        ord_pos[c] = run;
+        run += ord_cnt[c];
+      }
+    }
+    wsync();
+    for (int gi = lane; gi < a.nblocks; gi += 64) a.grp_order[atomicAdd(&ord_pos[15 - (int)(((long long)a.grp_cost[gi] * 16) / M)], 1)] = gi;
+    if (lane == 0) st->order_valid = 1;
+  }
   if (threadIdx.x != 0) return;
 
   LmHot L = st->hot;  // private register copy
