@@ -93,6 +93,7 @@ struct PassArgs {
   int partial_pitch;        // >= number of groups
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
   int stage_grow;           // rings served from the LDS stage (0: none)
+  int long_row;             // rows with more points than this are never staged
   unsigned long long* dbg_stamps;  // diagnostic build only: [wave][16] s_memtime stamps, or null
 };
 
@@ -261,12 +262,12 @@ __device__ __forceinline__ double wave_sum(double v) {
 //            Mahalanobis, residual / Jacobian / normal equations.
 // Waves never synchronise with each other inside the loop; the only barrier is the final block-level
 // reduction.  Partials are stored slot-major ([slot][block]) so the solver reads them coalesced.
-constexpr int kStageCap = 640;       // target points per wave stage (10 KB)
+constexpr int kStageCap = 64;       // target points per wave stage (10 KB)
 constexpr int kStageRowsPerLane = 4;
 constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
 constexpr int kStageXs = 20;         // cells per row of the staged region
 constexpr int kStageMaxGrow = 6;
-constexpr int kStageLongRow = 192;   // rows longer than this are not staged
+constexpr int kStageLongRow = 0;     // rows longer than this are not staged (0: no point staging at all, measured fastest)
 constexpr int kInnerRows = 100;      // rows of the inner box (query cells +- 1): 10 x 10
 constexpr int kInnerXs = 15;         // its cells per row (16 offsets = 16 lanes)
 
@@ -446,6 +447,28 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     const int i = qbase + lane;
     const bool mine = lane < qcount;
     NG_STAMP(1);
+    // ---- the tail's operands (one query per lane) are requested up front: their round trips (source point -> covariance;
+    //      old correspondence -> old target point) overlap the staging and the search.  The kernel is LDS-bound at two
+    //      waves per SIMD, so the ~35 registers this holds across the search are free ----
+    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j_old = -1;
+    double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
+    float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mine) {
+      sp = a.qpts[i];
+      if (do_err) {
+        j_old = corr_old[i];
+        const double* M = mahal_old + (size_t)i * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) Mold[e] = M[e];
+      }
+      if (do_lin) {
+        const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ca[e] = CA[e];
+      }
+      if (j_old >= 0) bp_old = a.tgt[j_old];
+    }
 
     if (do_lin && (a.mode & 8)) {  // DEBUG timing build: fake search result
       mypos = (qbase + lane) % 1000;
@@ -535,7 +558,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
                 // long rows (a dense scan line along x) stay in global memory and are read through x-windows; a row
                 // that would overflow the slice is skipped without consuming space, so shorter ones behind it still fit
                 int o = 0;
-                bool fits = rn[k] <= kStageLongRow;
+                bool fits = rn[k] <= a.long_row;
                 if (fits) {
                   o = atomicAdd(&S.alloc, rn[k]);
                   fits = o + rn[k] <= kStageCap;
@@ -724,27 +747,6 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       mybest = __shfl(best, src_lane);
       mypos = __shfl(pos, src_lane);
     }
-    // ---- tail: one query per lane.  Its operands are fetched only now: holding them across the search costs ~40
-    //      registers (and with them a resident wave per SIMD), more than the one round trip it would hide ----
-    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j_old = -1;
-    double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
-    float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mine) {
-      sp = a.qpts[i];
-      if (do_err) {
-        j_old = corr_old[i];
-        const double* M = mahal_old + (size_t)i * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) Mold[e] = M[e];
-      }
-      if (do_lin) {
-        const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) ca[e] = CA[e];
-      }
-      if (j_old >= 0) bp_old = a.tgt[j_old];
-    }
     double acc[kNumSums];
 #pragma unroll
     for (int v = 0; v < kNumSums; ++v) acc[v] = 0.0;
@@ -826,7 +828,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     //      of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips.
     {
       wave_lds_sync();
-      double* red = reinterpret_cast<double*>(S.pts);  // [32][30] doubles
+      double* red = reinterpret_cast<double*>(&S);  // [32][30] doubles over the whole (now idle) stage
       if (lane < 32) {
 #pragma unroll
         for (int v = 0; v < kNumSums; ++v) red[lane * 30 + v] = acc[v];
@@ -844,7 +846,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   {
     // counters: [3][64] through LDS, lanes 29..31 add their column
     wave_lds_sync();
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(S.pts);
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(&S);
     cnt[lane] = ncand;
     cnt[64 + lane] = nvalid;
     cnt[128 + lane] = nstaged;
