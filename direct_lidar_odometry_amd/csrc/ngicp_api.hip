@@ -527,8 +527,6 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
     int need = kStageMaxGrow;
     if (h->p.max_corr_dist < 1e30) need = (int)std::ceil(h->p.max_corr_dist / (double)T.grid.h);
     a.stage_grow = h->stage_grow <= 0 ? 0 : std::max(1, std::min(std::min(kStageMaxGrow, h->stage_grow), need));  // 0: search straight from global memory
-    a.long_row = kStageLongRow;
-    if (const char* e = std::getenv("NGICP_LONG_ROW")) a.long_row = std::max(0, std::atoi(e));
   }
 
   SolveArgs& s = c.sa;

@@ -93,7 +93,6 @@ struct PassArgs {
   int partial_pitch;        // >= number of groups
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
   int stage_grow;           // rings served from the LDS stage (0: none)
-  int long_row;             // rows with more points than this are never staged
   unsigned long long* dbg_stamps;  // diagnostic build only: [wave][16] s_memtime stamps, or null
 };
 
@@ -262,21 +261,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 //            Mahalanobis, residual / Jacobian / normal equations.
 // Waves never synchronise with each other inside the loop; the only barrier is the final block-level
 // reduction.  Partials are stored slot-major ([slot][block]) so the solver reads them coalesced.
-constexpr int kStageCap = 64;       // target points per wave stage (10 KB)
 constexpr int kStageRowsPerLane = 4;
 constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
 constexpr int kStageXs = 20;         // cells per row of the staged region
 constexpr int kStageMaxGrow = 6;
-constexpr int kStageLongRow = 0;     // rows longer than this are not staged (0: no point staging at all, measured fastest)
-constexpr int kInnerRows = 100;      // rows of the inner box (query cells +- 1): 10 x 10
-constexpr int kInnerXs = 15;         // its cells per row (16 offsets = 16 lanes)
 
 struct WaveStage {
-  float4 pts[kStageCap];   // staged target points (as stored: w = original index); reused by the final reduction
-  int4 live[kStageRows];   // one record per NON-EMPTY row: {y | z << 16, lds_begin | lds_end << 16, global_pos - lds_pos, 0}
-  unsigned short row_live[kStageRows];                   // region row -> index into live[], 0xffff = empty row
-  unsigned short cell_off[kInnerRows * (kInnerXs + 1)];  // inner box: LDS position of the first point of each cell
-  int alloc;               // bump allocator of pts[]
+  union {
+    struct {
+      int4 live[kStageRows];  // one record per NON-EMPTY row of the region, nearest ring first: {y | z << 16, points, first point, -}
+      unsigned short row_live[kStageRows];  // region row -> index into live[], 0xffff = empty row
+    };
+    double red[32 * 30];  // the per-batch reduction reuses the (then idle) tables as scratch
+  };
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -285,59 +282,24 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Scan staged LDS positions [ps, pe) of a row whose global position offset is `base` (pos = base + p).
-__device__ __forceinline__ void scan_stage_range(const WaveStage& S, int ps, int pe, int base, float qx, float qy, float qz, float& best, int& pos,
-                                                 unsigned int& ncand) {
-  ncand += (unsigned)(pe - ps);
-  for (int p = ps; p < pe; p += 4) {
-    const int p1 = min(p + 1, pe - 1), p2 = min(p + 2, pe - 1), p3 = min(p + 3, pe - 1);
-    const float4 a0 = S.pts[p], a1 = S.pts[p1], a2 = S.pts[p2], a3 = S.pts[p3];
-    const float d0 = sqdist(qx, qy, qz, a0), d1 = sqdist(qx, qy, qz, a1), d2 = sqdist(qx, qy, qz, a2), d3 = sqdist(qx, qy, qz, a3);
-    if (nn_better(d0, base + p, best, pos)) { best = d0; pos = base + p; }
-    if (nn_better(d1, base + p1, best, pos)) { best = d1; pos = base + p1; }
-    if (nn_better(d2, base + p2, best, pos)) { best = d2; pos = base + p2; }
-    if (nn_better(d3, base + p3, best, pos)) { best = d3; pos = base + p3; }
-  }
+// lower bound of the squared distance from a query (cell row cy, cz) to anything in grid row (ry, rz): the (y,z) gap to its cells
+__device__ __forceinline__ float row_gap_sq(const Grid& g, int ry, int rz, int cy, int cz, float qy, float qz) {
+  float gy = 0.f, gz = 0.f;
+  if (ry > cy) gy = (g.oy + (float)ry * g.h) - qy; else if (ry < cy) gy = qy - (g.oy + (float)(ry + 1) * g.h);
+  if (rz > cz) gz = (g.oz + (float)rz * g.h) - qz; else if (rz < cz) gz = qz - (g.oz + (float)(rz + 1) * g.h);
+  gy = fmaxf(gy - g.slack, 0.f);
+  gz = fmaxf(gz - g.slack, 0.f);
+  return gy * gy + gz * gz;
 }
 
-// A (y,z) row is sorted by x.  Scan the part of the staged row [ps, pe) that can still beat `best`: start at the
-// lower bound of qx - r (bisection), stop once x - qx > r, with r = sqrt(min(best, gate) - gyz) re-evaluated as
-// best improves.  Short rows are scanned whole.
-__device__ __forceinline__ void scan_stage_row_x(const WaveStage& S, int ps, int pe, int base, float qx, float qy, float qz, float gyz, float gate_sq,
-                                                 float& best, int& pos, unsigned int& ncand) {
-  if (pe - ps > 16) {
-    const float lim = fminf(best, gate_sq);
-    if (lim < 1.0e30f) {
-      const float xlo = qx - sqrtf(fmaxf(lim - gyz, 0.f));
-      int lo = ps, hi = pe;  // first index whose x >= xlo
-      while (hi - lo > 4) {
-        const int mid = (lo + hi) >> 1;
-        if (S.pts[mid].x < xlo) lo = mid; else hi = mid;
-      }
-      ps = lo;
-    }
-  }
-  int p = ps;
-  for (; p < pe; p += 4) {
-    const int p1 = min(p + 1, pe - 1), p2 = min(p + 2, pe - 1), p3 = min(p + 3, pe - 1);
-    const float4 a0 = S.pts[p], a1 = S.pts[p1], a2 = S.pts[p2], a3 = S.pts[p3];
-    const float d0 = sqdist(qx, qy, qz, a0), d1 = sqdist(qx, qy, qz, a1), d2 = sqdist(qx, qy, qz, a2), d3 = sqdist(qx, qy, qz, a3);
-    if (nn_better(d0, base + p, best, pos)) { best = d0; pos = base + p; }
-    if (nn_better(d1, base + p1, best, pos)) { best = d1; pos = base + p1; }
-    if (nn_better(d2, base + p2, best, pos)) { best = d2; pos = base + p2; }
-    if (nn_better(d3, base + p3, best, pos)) { best = d3; pos = base + p3; }
-    const float dx = a3.x - qx;  // the largest x of this step
-    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) { p += 4; break; }
-  }
-  ncand += (unsigned)(min(p, pe) - ps);
-}
 // Outward scan of an x-sorted run [s, e) in GLOBAL memory from a starting guess m: walk right, then left, each until the
 // x-gap alone rules the rest out.  Any start is correct (a side only stops once it is past qx AND out of reach); a good
 // start (interpolated from the cell geometry: points of a dense scan line are nearly equidistant in x) makes the cost
 // O(points within reach) with no search at all.  This is what keeps dense scan lines affordable.
 __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
-                                                    float& best, int& pos, unsigned int& ncand) {
+                                                    float& best, int& pos, unsigned int& ncand, unsigned int& gsteps) {
   if (e <= s) return;
+  gsteps += 0x10000u;
   m = min(max(m, s), e - 1);
   for (int p = m; p < e; p += 8) {  // rightwards, 8 loads in flight
     float4 c[8];
@@ -353,6 +315,7 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
       if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
     }
     ncand += 8;
+    ++gsteps;
     const float dx = c[7].x - qx;
     if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
   }
@@ -370,27 +333,10 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
       if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
     }
     ncand += 8;
+    ++gsteps;
     const float dx = qx - c[7].x;
     if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
   }
-}
-
-// the same for a run [s, e) of the x-sorted row in global memory
-__device__ __forceinline__ void scan_global_row_x(const float4* __restrict__ tgt, int s, int e, float qx, float qy, float qz, float gyz, float gate_sq,
-                                                  float& best, int& pos, unsigned int& ncand) {
-  int p = s;
-  for (; p < e; p += 4) {
-    const int p1 = min(p + 1, e - 1), p2 = min(p + 2, e - 1), p3 = min(p + 3, e - 1);
-    const float4 a0 = tgt[p], a1 = tgt[p1], a2 = tgt[p2], a3 = tgt[p3];
-    const float d0 = sqdist(qx, qy, qz, a0), d1 = sqdist(qx, qy, qz, a1), d2 = sqdist(qx, qy, qz, a2), d3 = sqdist(qx, qy, qz, a3);
-    if (nn_better(d0, p, best, pos)) { best = d0; pos = p; }
-    if (nn_better(d1, p1, best, pos)) { best = d1; pos = p1; }
-    if (nn_better(d2, p2, best, pos)) { best = d2; pos = p2; }
-    if (nn_better(d3, p3, best, pos)) { best = d3; pos = p3; }
-    const float dx = a3.x - qx;
-    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) { p += 4; break; }
-  }
-  ncand += (unsigned)(min(p, e) - s);
 }
 
 #define NG_STAMP(k)                                                                                   \
@@ -506,14 +452,10 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         cell_coords(g, mx - ex, my - ey, mz - ez, b0x, b0y, b0z);
         cell_coords(g, mx + ex, my + ey, mz + ez, b1x, b1y, b1z);
       }
-      // inner box: box cells +- 1 (the ring-1 windows of every query of the batch)
-      const int iX0 = max(b0x - 1, 0), iY0 = max(b0y - 1, 0), iZ0 = max(b0z - 1, 0);
-      const int iX1 = min(b1x + 1, g.nx - 1), iY1 = min(b1y + 1, g.ny - 1), iZ1 = min(b1z + 1, g.nz - 1);
-      const int iwy = iY1 - iY0 + 1, irows = iwy * (iZ1 - iZ0 + 1), iXS = iX1 - iX0 + 1;
-      int X0 = 0, Y0 = 0, Z0 = 0, wy = 1, grow = 0, nlive = 0;
-      bool staged = false, listed = false;
-      if (a.stage_grow >= 1 && irows <= kInnerRows && iXS <= kInnerXs) {
-        int XS, rows;
+      int X0 = 0, Y0 = 0, Z0 = 0, XS = 1, wy = 1, grow = 0, nlive = 0;
+      bool listed = false;
+      if (a.stage_grow >= 1) {
+        int rows;
         for (grow = a.stage_grow;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
           X0 = max(b0x - grow, 0);
           Y0 = max(b0y - grow, 0);
@@ -526,9 +468,8 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         }
         if (rows <= kStageRows && XS <= kStageXs) {
           // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target, and the
-          // row's ring distance from the batch box (rows are staged and listed nearest ring first)
-          int rb[kStageRowsPerLane], rs[kStageRowsPerLane], rn[kStageRowsPerLane], ro[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane];
-          bool rst[kStageRowsPerLane];
+          // row's ring distance from the batch box (rows are listed nearest ring first)
+          int rb[kStageRowsPerLane], rs[kStageRowsPerLane], rn[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane];
 #pragma unroll
           for (int k = 0; k < kStageRowsPerLane; ++k) {
             const int r = lane + 64 * k;
@@ -540,14 +481,9 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
             rn[k] = ev - sv;
             rho[k] = max(max(b0y - ry, ry - b1y), max(max(b0z - rz, rz - b1z), 0));
             ryz[k] = ry | (rz << 16);
-            ro[k] = 0;
-            rst[k] = false;
           }
-          wave_lds_sync();  // the previous batch's readers are done with the slice
-          if (lane == 0) S.alloc = 0;
-          wave_lds_sync();
-          // ring by ring: list the non-empty rows and give them LDS space until the slice is full (rows that do
-          // not fit stay in global memory; they are the far ones and few of them survive pruning)
+          wave_lds_sync();  // the previous batch's readers are done with the tables (and with the reduction scratch)
+          // ring by ring: the non-empty rows, nearest ring first
           for (int lev = 0; lev <= grow; ++lev) {
 #pragma unroll
             for (int k = 0; k < kStageRowsPerLane; ++k) {
@@ -555,19 +491,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
               const unsigned long long m = __ballot(on);
               if (on) {
                 const int li = nlive + __popcll(m & ((1ull << lane) - 1ull));
-                // long rows (a dense scan line along x) stay in global memory and are read through x-windows; a row
-                // that would overflow the slice is skipped without consuming space, so shorter ones behind it still fit
-                int o = 0;
-                bool fits = rn[k] <= a.long_row;
-                if (fits) {
-                  o = atomicAdd(&S.alloc, rn[k]);
-                  fits = o + rn[k] <= kStageCap;
-                  if (!fits) atomicSub(&S.alloc, rn[k]);
-                }
-                rst[k] = fits;
-                ro[k] = o;
-                // record: {y | z << 16, staged ? (lds_begin | lds_end << 16) : -count, staged ? global - lds : global_begin, 0}
-                S.live[li] = rst[k] ? make_int4(ryz[k], o | ((o + rn[k]) << 16), rs[k] - o, 0) : make_int4(ryz[k], -rn[k], rs[k], 0);
+                S.live[li] = make_int4(ryz[k], rn[k], rs[k], 0);  // {y | z << 16, points, first point, -}
                 S.row_live[lane + 64 * k] = (unsigned short)li;
               }
               nlive += __popcll(m);
@@ -576,76 +500,14 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 #pragma unroll
           for (int k = 0; k < kStageRowsPerLane; ++k)
             if (rn[k] == 0 && lane + 64 * k < rows) S.row_live[lane + 64 * k] = 0xffffu;
-          staged = true;
           listed = true;
-          // staged rows are contiguous runs of the cell-sorted target.  Short rows (the common case in sparse regions)
-          // are copied by their owner lane, all lanes in parallel, 8 loads in flight per row; longer rows go by LDS-DMA,
-          // one wave-wide piece per 64 points (row parameters travel by v_readlane).
-#pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k) {
-            const bool shortrow = rst[k] && rn[k] > 0 && rn[k] <= 8;
-#pragma unroll
-            for (int j0 = 0; j0 < 8; j0 += 4) {
-              float4 v[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = (shortrow && j0 + j < rn[k]) ? a.tgt[rs[k] + j0 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (shortrow && j0 + j < rn[k]) S.pts[ro[k] + j0 + j] = v[j];
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k) {
-            unsigned long long live = __ballot(rst[k] && rn[k] > 8);
-            while (live) {
-              const int rl = __builtin_ctzll(live);
-              live &= live - 1;
-              const int cnt = __builtin_amdgcn_readlane(rn[k], rl), src0 = __builtin_amdgcn_readlane(rs[k], rl);
-              const int dst0 = __builtin_amdgcn_readlane(ro[k], rl);
-              for (int j0 = 0; j0 < cnt; j0 += 64) {
-                if (j0 + lane < cnt)
-                  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(a.tgt + src0 + j0 + lane),
-                                                   (void __attribute__((address_space(3)))*)(S.pts + dst0 + j0), 16, 0, 0);
-              }
-            }
-          }
-          // per-cell offsets of the staged rows of the inner box (lanes along x); the stores are deferred so that the
-          // loads of four rows overlap
-          int pend_i[4], pend_v[4], pend_o[4];
-          int npend = 0;
-#pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k) {
-            unsigned long long live = __ballot(rst[k] && rn[k] > 0 && rho[k] <= 1);
-            while (live) {
-              const int rl = __builtin_ctzll(live);
-              live &= live - 1;
-              const int yz = __builtin_amdgcn_readlane(ryz[k], rl);
-              const int y = yz & 0xffff, z = yz >> 16;
-              if (y >= iY0 && y <= iY1 && z >= iZ0 && z <= iZ1) {
-                const int base = __builtin_amdgcn_readlane(rb[k], rl);
-                pend_i[npend] = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
-                pend_o[npend] = __builtin_amdgcn_readlane(ro[k], rl) - __builtin_amdgcn_readlane(rs[k], rl);
-                pend_v[npend] = (lane <= iXS) ? a.tgt_cell_start[base + (iX0 - X0) + lane] : 0;
-                if (++npend == 4) {
-#pragma unroll
-                  for (int u = 0; u < 4; ++u)
-                    if (lane <= iXS) S.cell_off[pend_i[u] + lane] = (unsigned short)(pend_v[u] + pend_o[u]);
-                  npend = 0;
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (u < npend && lane <= iXS) S.cell_off[pend_i[u] + lane] = (unsigned short)(pend_v[u] + pend_o[u]);
-          __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): the DMA pieces have landed
           wave_lds_sync();
         }
       }
       NG_STAMP(3);
       if (a.dbg_stamps && lane == 0) {
         unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
-        d[10] = (unsigned long long)(staged ? grow : 0);
+        d[10] = (unsigned long long)(listed ? grow : 0);
         d[11] = (unsigned long long)nlive;
         d[12] = (unsigned long long)qcount;
         d[13] = (unsigned long long)((b1x - b0x + 1) | ((b1y - b0y + 1) << 8) | ((b1z - b0z + 1) << 16));
@@ -653,41 +515,38 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       if (qok) {
         int rdone = 1;  // rings 0..rdone have been searched exhaustively
         // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
-        // simply takes the global path
+        // simply takes the unindexed path
         const bool in_box = listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
-        if (in_box && staged) {
+        unsigned int dbg_g1 = 0, dbg_g2 = 0;
+        if (in_box) {
           if (sub == 0) ++nstaged;
-          // ---- rings 0..1 out of LDS: lane `sub` takes rows sub, sub + G, ... of the 3 x 3 (y,z) window ----
-          const int c0 = max(cx - 1, 0) - iX0, c1 = min(cx + 1, g.nx - 1) - iX0 + 1;
-          // rows of the 3 x 3 window, nearest first (own row, then the four edge neighbours, then the corners), so that
-          // the later rows are pruned by their (y,z) gap against a best that is already tight
+          // ---- rings 0..1: lane `sub` takes rows sub, sub + G, ... of the 3 x 3 (y,z) window, nearest first (own row,
+          //      then the four edge neighbours, then the corners), so that the later rows are pruned by their (y,z) gap
+          //      against a best that is already tight.  A row's three cells are one x-sorted run: the walk starts where
+          //      qx would sit if its points were equidistant and goes outward until the x-gap rules the rest out ----
+          const int cxa = max(cx - 1, 0), cxb = min(cx + 1, g.nx - 1) + 1;
+          const float frac = fminf(fmaxf((qx - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+          constexpr int NR = (9 + G - 1) / G;
+          int r_s[NR], r_e[NR];
+          float r_g[NR];
 #pragma unroll
-          for (int k = 0; k < (9 + G - 1) / G; ++k) {
+          for (int k = 0; k < NR; ++k) {  // the bounds of all the lane's rows in one round trip
             const int order = sub + k * G;                          // 0..8 in visiting order
             const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
             const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-            if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-              float gy = 0.f, gz = 0.f;
-              if (y > cy) gy = (g.oy + (float)y * g.h) - qy; else if (y < cy) gy = qy - (g.oy + (float)(y + 1) * g.h);
-              if (z > cz) gz = (g.oz + (float)z * g.h) - qz; else if (z < cz) gz = qz - (g.oz + (float)(z + 1) * g.h);
-              gy = fmaxf(gy - g.slack, 0.f);
-              gz = fmaxf(gz - g.slack, 0.f);
-              const float gyz = gy * gy + gz * gz;
-              const int li = S.row_live[(z - Z0) * wy + (y - Y0)];
-              if (li != 0xffff && gyz <= fminf(best, a.gate_sq_f)) {  // empty rows carry no cell offsets
-                const int4 rec = S.live[li];
-                if (rec.y >= 0) {
-                  const int ci = ((z - iZ0) * iwy + (y - iY0)) * (kInnerXs + 1);
-                  scan_stage_range(S, S.cell_off[ci + c0], S.cell_off[ci + c1], rec.z, qx, qy, qz, best, pos, ncand);
-                } else {  // a row that was not staged (dense scan line): its three cells from global memory
-                  const int rowb = (z * g.ny + y) * g.nx;
-                  const int s0 = a.tgt_cell_start[rowb + c0 + iX0], e0 = a.tgt_cell_start[rowb + c1 + iX0];
-                  // start where qx would sit if the window's points were equidistant in x
-                  const float xl = g.ox + (float)(c0 + iX0) * g.h, frac = (qx - xl) / ((float)(c1 - c0) * g.h);
-                  scan_global_outward(a.tgt, s0, e0, s0 + (int)(fminf(fmaxf(frac, 0.f), 1.f) * (float)(e0 - s0)), qx, qy, qz, gyz, a.gate_sq_f, best, pos, ncand);
-                }
-              }
+            r_s[k] = r_e[k] = 0;
+            r_g[k] = 0.f;
+            if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny && S.row_live[(z - Z0) * wy + (y - Y0)] != 0xffff) {
+              const int rowb = (z * g.ny + y) * g.nx;
+              r_g[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
+              r_s[k] = a.tgt_cell_start[rowb + cxa];
+              r_e[k] = a.tgt_cell_start[rowb + cxb];
             }
+          }
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            if (r_e[k] > r_s[k] && r_g[k] <= fminf(best, a.gate_sq_f))
+              scan_global_outward(a.tgt, r_s[k], r_e[k], r_s[k] + (int)(frac * (float)(r_e[k] - r_s[k])), qx, qy, qz, r_g[k], a.gate_sq_f, best, pos, ncand, dbg_g1);
             if (k == 0 && G > 1) group_min<G>(best, pos);  // both lanes continue from the better of the two nearest rows
           }
           if (G > 1) group_min<G>(best, pos);
@@ -696,48 +555,34 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         }
         NG_STAMP(4);
         const unsigned int dbg_c1 = ncand;
-        unsigned int dbg_rows = 0, dbg_urows = 0;
-        if (in_box) {
+        unsigned int dbg_rows = 0;
+        if (in_box && grow >= 2) {
           // ---- rings 2..grow: the listed rows (nearest ring first) that can still hold a closer point ----
-          if (grow >= 2) {
-            const float bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-            if (!(best <= bound1 || bound1 >= a.gate_sq_f)) {
-              for (int li = sub; li < nlive; li += G) {
-                const int4 rec = S.live[li];
-                const int ry = rec.x & 0xffff, rz = rec.x >> 16;
-                // lower bound of the distance from q to anything in row (ry, rz): the (y,z) gap to its cells
-                float gy = 0.f, gz = 0.f;
-                if (ry > cy) gy = (g.oy + (float)ry * g.h) - qy; else if (ry < cy) gy = qy - (g.oy + (float)(ry + 1) * g.h);
-                if (rz > cz) gz = (g.oz + (float)rz * g.h) - qz; else if (rz < cz) gz = qz - (g.oz + (float)(rz + 1) * g.h);
-                gy = fmaxf(gy - g.slack, 0.f);
-                gz = fmaxf(gz - g.slack, 0.f);
-                const float gyz = gy * gy + gz * gz;
-                if (gyz > fminf(best, a.gate_sq_f)) continue;
-                ++dbg_rows;
-                if (rec.y < 0) ++dbg_urows;
-                if (rec.y >= 0) {
-                  scan_stage_row_x(S, rec.y & 0xffff, (int)((unsigned)rec.y >> 16), rec.z, qx, qy, qz, gyz, a.gate_sq_f, best, pos, ncand);
-                } else {
-                  // the row did not fit the slice (a dense scan line): outward from where qx sits among the three centre
-                  // cells (interpolated), over the whole region row
-                  const int rowb = (rz * g.ny + ry) * g.nx;
-                  const int ca = max(cx - 1, 0), cb = min(cx + 1, g.nx - 1) + 1;
-                  const int s0 = a.tgt_cell_start[rowb + ca], e0 = a.tgt_cell_start[rowb + cb];
-                  const float xl = g.ox + (float)ca * g.h, frac = (qx - xl) / ((float)(cb - ca) * g.h);
-                  scan_global_outward(a.tgt, rec.z, rec.z - rec.y, s0 + (int)(fminf(fmaxf(frac, 0.f), 1.f) * (float)(e0 - s0)), qx, qy, qz, gyz, a.gate_sq_f, best,
-                                      pos, ncand);
-                }
-              }
-              if (G > 1) group_min<G>(best, pos);
-              rdone = grow;
+          const float bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
+          if (!(best <= bound1 || bound1 >= a.gate_sq_f)) {
+            const int cxa = max(cx - 1, 0), cxb = min(cx + 1, g.nx - 1) + 1;
+            const float frac3 = fminf(fmaxf((qx - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+            for (int li = sub; li < nlive; li += G) {
+              const int4 rec = S.live[li];
+              // lower bound of the distance from q to anything in row (ry, rz): the (y,z) gap to its cells
+              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz);
+              if (gyz > fminf(best, a.gate_sq_f)) continue;
+              ++dbg_rows;
+              // start where qx sits among the row's three centre cells (one extra round trip, but a much better start
+              // than interpolating over the whole region row: the walk is over the whole row either way)
+              const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
+              const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
+              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), qx, qy, qz, gyz, a.gate_sq_f, best, pos, ncand, dbg_g2);
             }
+            if (G > 1) group_min<G>(best, pos);
+            rdone = grow;
           }
         }
         NG_STAMP(5);
         if (a.dbg_stamps) {
           unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
-          atomicMax(&d[14], (unsigned long long)(ncand - dbg_c1) | ((unsigned long long)dbg_rows << 32) | ((unsigned long long)dbg_urows << 48));
-          atomicMax(&d[15], (unsigned long long)dbg_c1);
+          atomicMax(&d[14], ((unsigned long long)(dbg_g2 & 0xffff) << 48) | ((unsigned long long)(dbg_g2 >> 16) << 32) | ((unsigned long long)dbg_rows << 16) | (ncand - dbg_c1));
+          atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
         }
         nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, rdone, best, pos, ncand);
       }
@@ -828,7 +673,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     //      of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips.
     {
       wave_lds_sync();
-      double* red = reinterpret_cast<double*>(&S);  // [32][30] doubles over the whole (now idle) stage
+      double* red = S.red;  // [32][30] doubles
       if (lane < 32) {
 #pragma unroll
         for (int v = 0; v < kNumSums; ++v) red[lane * 30 + v] = acc[v];
@@ -846,7 +691,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   {
     // counters: [3][64] through LDS, lanes 29..31 add their column
     wave_lds_sync();
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(&S);
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(S.red);
     cnt[lane] = ncand;
     cnt[64 + lane] = nvalid;
     cnt[128 + lane] = nstaged;
