@@ -301,12 +301,15 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
   if (e <= s) return;
   gsteps += 0x10000u;
   m = min(max(m, s), e - 1);
-  for (int p = m; p < e; p += 8) {  // rightwards, 8 loads in flight
+  // first round trip: the 8 points around the start.  Most walks end here: both neighbours of the window are ruled out by
+  // their x-gap alone.
+  bool go_right, go_left;
+  {
     float4 c[8];
     int idx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      idx[j] = min(p + j, e - 1);
+      idx[j] = min(max(m - 4 + j, s), e - 1);
       c[j] = tgt[idx[j]];
     }
 #pragma unroll
@@ -316,27 +319,48 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
     }
     ncand += 8;
     ++gsteps;
-    const float dx = c[7].x - qx;
-    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
+    const float lim = fminf(best, gate_sq), dr = c[7].x - qx, dl = qx - c[0].x;
+    go_right = m + 4 < e && !(dr > 0.f && dr * dr + gyz > lim);
+    go_left = m - 5 >= s && !(dl > 0.f && dl * dl + gyz > lim);
   }
-  for (int p = m - 1; p >= s; p -= 8) {  // leftwards
-    float4 c[8];
-    int idx[8];
+  if (go_right)
+    for (int p = m + 4; p < e; p += 8) {  // rightwards, 8 loads in flight
+      float4 c[8];
+      int idx[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      idx[j] = max(p - j, s);
-      c[j] = tgt[idx[j]];
-    }
+      for (int j = 0; j < 8; ++j) {
+        idx[j] = min(p + j, e - 1);
+        c[j] = tgt[idx[j]];
+      }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = sqdist(qx, qy, qz, c[j]);
-      if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
+      for (int j = 0; j < 8; ++j) {
+        const float d = sqdist(qx, qy, qz, c[j]);
+        if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
+      }
+      ncand += 8;
+      ++gsteps;
+      const float dx = c[7].x - qx;
+      if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
     }
-    ncand += 8;
-    ++gsteps;
-    const float dx = qx - c[7].x;
-    if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
-  }
+  if (go_left)
+    for (int p = m - 5; p >= s; p -= 8) {  // leftwards
+      float4 c[8];
+      int idx[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        idx[j] = max(p - j, s);
+        c[j] = tgt[idx[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = sqdist(qx, qy, qz, c[j]);
+        if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
+      }
+      ncand += 8;
+      ++gsteps;
+      const float dx = qx - c[7].x;
+      if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
+    }
 }
 
 #define NG_STAMP(k)                                                                                   \

@@ -2,7 +2,7 @@ import sys, numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16).astype(np.float64)
 a = a[a[:, 0] > 0]
 t0 = a[:, 0].min()
-names = ["entry", "prologue loads", "query cells", "staged", "ring1 done", "far rows done", "shells done", "loop end", "reduce done", "barrier"]
+names = ["entry", "prologue loads", "query cells", "rows listed", "ring1 done", "far rows done", "shells done", "loop end", "reduce done", "barrier"]
 print("waves", len(a), " kernel span (cycles):", a[:, :10].max() - t0)
 print("wave start offset percentiles [0,50,90,100]:", np.percentile(a[:, 0] - t0, [0, 50, 90, 100]).round(0))
 prev = a[:, 0]
@@ -32,5 +32,5 @@ for w in order:
     d = [a[w, k] - a[w, k - 1] if a[w, k] > 0 and a[w, k-1] > 0 else -1 for k in range(1, 9)]
     x14 = int(a[w, 14]); x15 = int(a[w, 15])
     print(int(life[w]), [int(x) for x in d], int(g[w]), int(nl[w]), int(qc[w]), (int(bb[w]) & 255, (int(bb[w]) >> 8) & 255, (int(bb[w]) >> 16) & 255),
-          "max-lane: ring1 cand", x15, "far cand", x14 & 0xffffffff, "far rows", (x14 >> 32) & 0xffff, "unstaged", x14 >> 48)
-print("sum of wave lifetimes (to reduce-done):", life.sum(), " / 2048 slots =", life.sum() / 2048)
+          "max-lane ring1: steps", x15 >> 48, "rows", (x15 >> 32) & 0xffff, "cand", x15 & 0xffffffff, "| far: steps", x14 >> 48, "walked", (x14 >> 32) & 0xffff, "rows", (x14 >> 16) & 0xffff, "cand", x14 & 0xffff)
+print("sum of wave lifetimes (to reduce-done):", life.sum(), " / 3072 slots =", life.sum() / 3072)
