@@ -144,6 +144,7 @@ struct ngicp {
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
   bool profiling = false;
+  int prof_stride = 1;      // time every prof_stride-th pass launch (events between kernels cost a few microseconds each)
 
   Slot src, tgt;
   CovSet src_covs, tgt_covs;
@@ -635,7 +636,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       }
     }
     for (int i = 0; i < chunk && launched < max_passes; ++i, ++launched) {
-      const bool timed = h->profiling && (size_t)(2 * launched + 1) < h->prof_events.size();
+      const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
       if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched], h->stream));
       launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
       if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched + 1], h->stream));
@@ -705,11 +706,15 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   if (h->profiling) {
     // HIP events on the handle's own stream around every pass launch that did work
     const long timed = std::min<long>(st.hot.passes, (long)h->prof_events.size() / 2);
-    for (long i = 0; i < timed; ++i) {
+    int counted = 0;
+    for (long i = h->prof_stride / 2; i < timed; i += h->prof_stride) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, h->prof_events[2 * i], h->prof_events[2 * i + 1]) == hipSuccess) s.pass_ms_total += ms;
+      if (hipEventElapsedTime(&ms, h->prof_events[2 * i], h->prof_events[2 * i + 1]) == hipSuccess) {
+        s.pass_ms_total += ms;
+        ++counted;
+      }
     }
-    s.passes_timed = (int)timed;
+    s.passes_timed = counted;
   } else {
     s.passes_timed = 0;
   }
@@ -1120,6 +1125,7 @@ int ngicp_get_stats(ngicp_t* h, ngicp_stats* out) {
 int ngicp_set_profiling(ngicp_t* h, int on) {
   return guarded(h, [&] {
     h->profiling = on != 0;
+    h->prof_stride = on > 1 ? on : 1;
     if (h->profiling && h->prof_events.empty()) {
       h->prof_events.resize(2 * 1024);
       for (auto& e : h->prof_events) HIP_TRY(hipEventCreate(&e));

@@ -742,6 +742,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
 // --- the solver ----------------------------------------------------------------------------------
+constexpr int kMaxOrderGroups = 8192;  // launch-order sort: groups whose costs fit the solver's LDS
 constexpr int kSolveThreads = 256;  // 4 waves: keeps the full VGPR budget for the serial lane
 
 struct SolveArgs {
@@ -885,17 +886,29 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ double sums[kPartialStride];
   __shared__ double red_tile[kSolveThreads / 64][64 * 33];
   __shared__ int ord_cnt[16], ord_pos[16], ord_max;
+  __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
   if (a.mode == 0 && st->hot.done) return;
+  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
+  if (order_it)  // the groups' measured costs, for the launch order built further down (visible after the barriers below)
+    for (int gi = threadIdx.x; gi < a.nblocks; gi += kSolveThreads) ord_cost[gi] = a.grp_cost[gi];
 
   // ---- deterministic reduction of the block partials: all loads of a step in flight together, then a transpose
   //      through LDS (lane v adds column v in fixed order) instead of a butterfly of 64-bit LDS-crossbar shuffles ----
   double acc[kNumSlots];
 #pragma unroll
   for (int v = 0; v < kNumSlots; ++v) acc[v] = 0.0;
-  for (int b = threadIdx.x; b < a.nblocks; b += kSolveThreads) {
+  for (int b = threadIdx.x; b < a.nblocks; b += 2 * kSolveThreads) {  // two columns per step: 64 loads in flight per thread
+    const int b2 = b + kSolveThreads;
+    const bool has2 = b2 < a.nblocks;
+    double p0[kNumSlots], p1[kNumSlots];
 #pragma unroll
-    for (int v = 0; v < kNumSlots; ++v) acc[v] += a.partials[(size_t)v * a.pitch + b];
+    for (int v = 0; v < kNumSlots; ++v) {
+      p0[v] = a.partials[(size_t)v * a.pitch + b];
+      p1[v] = has2 ? a.partials[(size_t)v * a.pitch + b2] : 0.0;
+    }
+#pragma unroll
+    for (int v = 0; v < kNumSlots; ++v) acc[v] = (acc[v] + p0[v]) + p1[v];  // same order as one column at a time
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
@@ -924,10 +937,10 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __syncthreads();
   if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
   if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
-  if (a.mode == 0 && a.grp_order && wave == 1) {
-    // ---- launch order of the next pass, built by wave 1 while lane 0 runs the state machine: 16 cost classes
-    //      relative to the slowest group, heaviest class first.  The order inside a class is whatever the LDS
-    //      atomics make it: the pass's results do not depend on the launch order. ----
+  if (order_it && wave == 1) {
+    // ---- launch order of the next pass, built by wave 1 (costs already in LDS) while lane 0 runs the state machine:
+    //      16 cost classes relative to the slowest group, heaviest class first.  The order inside a class is whatever
+    //      the LDS atomics make it: the pass's results do not depend on the launch order. ----
     auto wsync = [] {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -937,11 +950,15 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
     if (lane == 0) ord_max = 1;
     wsync();
     int mx = 0;
-    for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, a.grp_cost[gi]);
+    for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, ord_cost[gi]);
     atomicMax(&ord_max, mx);
     wsync();
     const long long M = (long long)ord_max + 1;
-    for (int gi = lane; gi < a.nblocks; gi += 64) atomicAdd(&ord_cnt[15 - (int)(((long long)a.grp_cost[gi] * 16) / M)], 1);
+    for (int gi = lane; gi < a.nblocks; gi += 64) {
+      const int c = 15 - (int)(((long long)ord_cost[gi] * 16) / M);
+      ord_cost[gi] = c;  // the class replaces the cost
+      atomicAdd(&ord_cnt[c], 1);
+    }
     wsync();
     if (lane == 0) {
       int run = 0;
@@ -951,7 +968,7 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
       }
     }
     wsync();
-    for (int gi = lane; gi < a.nblocks; gi += 64) a.grp_order[atomicAdd(&ord_pos[15 - (int)(((long long)a.grp_cost[gi] * 16) / M)], 1)] = gi;
+    for (int gi = lane; gi < a.nblocks; gi += 64) a.grp_order[atomicAdd(&ord_pos[ord_cost[gi]], 1)] = gi;
     if (lane == 0) st->order_valid = 1;
   }
   if (threadIdx.x != 0) return;

@@ -332,8 +332,9 @@ class NanoGICP:
             self._ck(self._L.ngicp_get_lm_trace(self._h, _p(out, c_f64p), n.value, C.byref(n)))
         return out
 
-    def setProfiling(self, on: bool):
-        self._ck(self._L.ngicp_set_profiling(self._h, 1 if on else 0))
+    def setProfiling(self, on):
+        """False/0: off; True/1: HIP events around every pass launch; N > 1: around every N-th launch."""
+        self._ck(self._L.ngicp_set_profiling(self._h, int(on)))
 
     def stats(self) -> dict:
         s = Stats()

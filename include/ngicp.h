@@ -155,10 +155,11 @@ typedef struct ngicp_stats {
   int lanes_per_query;
   int passes_timed;         /* launches covered by pass_ms_total */
   long long n_src, n_tgt;   /* cloud sizes of the last align */
-  double staged_fraction;   /* fraction of queries whose inner rings were served from the LDS stage */
+  double staged_fraction;   /* fraction of queries served through the LDS row index of their batch region */
 } ngicp_stats;
 int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
-/* HIP-event timing of every k_gicp_pass launch inside align (two event records per launch; off by default) */
+/* HIP-event timing of the k_gicp_pass launches inside align (two event records per timed launch; off by default).
+   on = 1: every launch; on = N > 1: every N-th launch (an event between two kernels costs a few microseconds of stream time) */
 int ngicp_set_profiling(ngicp_t* h, int on);
 
 /* --- point-sharded multi-GPU stepping ------------------------ */
