@@ -7,7 +7,7 @@
 //           (NanoGICP::update_correspondences, impl/nano_gicp_impl.hpp:174-211)
 //       K3  residual, SE(3) Jacobian, H += J^T M J, b += J^T M e, y0 += e^T M e
 //           (NanoGICP::linearize, impl/nano_gicp_impl.hpp:214-270)
-//       R0  wavefront-shuffle -> LDS -> per-block partial sums (fixed order: deterministic)
+//       R0  LDS transpose -> per-group partial sums (fixed order: deterministic, independent of launch order)
 //   k_lm_solve    (one block)
 //       final reduction of the block partials, then the Levenberg-Marquardt / Gauss-Newton state
 //       machine of LsqRegistration (impl/lsq_registration_impl.hpp:89-208) on one lane: 6x6 LDLT,
@@ -244,23 +244,26 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // --- the fused pass ------------------------------------------------------------------------------
-// Work decomposition: a wave owns tile-aligned batches of up to 32 consecutive queries in Morton-tile
-// order (a compact 3-D blob; batches are cut at index-build time so that none leaves its tile).  Per batch:
-//   stage    the wave computes the batch's bounding box in target-cell coordinates, grows it by as many
-//            rings as fit (up to the number that covers the distance gate), and copies the NON-EMPTY (y,z)
-//            rows of that region into its private LDS slice: a row is ONE contiguous run of the cell-sorted
-//            target, moved by LDS-DMA (global_load_lds_dwordx4: no registers, all rows in flight together).
-//            The global reads of the search are two dependent round trips (row bounds; then points + the
-//            inner box's cell offsets), all wide and issued back to back;
-//   search   2 lanes per query scan the query's 27 cells out of LDS (ds_read_b128).  A query whose nearest
-//            point is not provably inside ring 1 then scans the staged rows that can still hold a closer
-//            point (row-level distance pruning; the list of non-empty rows is in LDS, so empty space costs
-//            nothing), which is exact for every ring the stage covers.  Only queries that need rings beyond
-//            the stage (dense regions that overflowed it) touch global memory in the search;
-//   tail     lanes 0..31, one query each, FP64: K4 error under the previous correspondences, gate,
-//            Mahalanobis, residual / Jacobian / normal equations.
-// Waves never synchronise with each other inside the loop; the only barrier is the final block-level
-// reduction.  Partials are stored slot-major ([slot][block]) so the solver reads them coalesced.
+// Work decomposition: a wave owns ONE tile-aligned batch of up to 32 consecutive queries in Morton-tile order (a
+// compact 3-D blob; batches are cut at index-build time so that none leaves its tile); a block is the four waves of
+// four consecutive batches (a GROUP: they share most of their target rows, and with them the CU's L1).  Per batch:
+//   index    the wave pushes the batch's bounding box through the trial pose, grows it by as many rings as fit the
+//            row table (up to the number that covers the distance gate) and fetches, in ONE round trip, the bounds
+//            of every (y,z) row of that region in the cell-sorted target (a row is one contiguous, x-sorted run).
+//            The NON-EMPTY rows go into an LDS list, nearest ring first: empty space costs nothing afterwards;
+//   search   2 lanes per query.  Ring 1: the bounds of the query's (up to 9) window rows come in one round trip, the
+//            rows are walked nearest first.  A walk starts where qx sits in the run (interpolated), fetches the 8
+//            points around it, and continues right / left, 8 points per round trip, only while the x-gap alone does
+//            not rule the rest out.  A query that is not provably exact after ring 1 walks the listed rows that can
+//            still hold a closer point ((y,z)-gap pruning); rings beyond the list use the global shell walk;
+//   tail     lanes 0..31, one query each, FP64: K4 error under the previous correspondences, gate, Mahalanobis,
+//            residual / Jacobian / normal equations.  Its operands were requested before the search.
+// Target points are NOT staged in LDS: measured on MI355X, copying a region's rows (LDS-DMA, 640 points per wave) cost
+// more than it saved - the 8 MB target lives in L2 / Infinity Cache, a walk touches 8-16 points of a row, and the LDS
+// the copies needed held occupancy at 8 waves per CU.  What pays is the row LIST (which rows exist, where they start)
+// and 12 waves per CU hiding the walks' latency.
+// Partial sums are stored per GROUP, slot-major ([slot][group]), so that (a) the solver reads them coalesced and (b)
+// the result does not depend on the order in which the groups are launched - which the solver sorts by measured cost.
 constexpr int kStageRowsPerLane = 4;
 constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
 constexpr int kStageXs = 20;         // cells per row of the staged region
