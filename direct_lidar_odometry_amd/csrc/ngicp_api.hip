@@ -143,6 +143,7 @@ struct ngicp {
   int lanes_per_query = 0;  // 0 = auto
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
+  std::pair<size_t, double> voxel_memo[2] = {{0, 0.0}, {0, 0.0}};  // {cloud size, auto voxel edge} of recent builds
   bool profiling = false;
   int prof_stride = 1;      // time every prof_stride-th pass launch (events between kernels cost a few microseconds each)
 
@@ -273,6 +274,10 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
     for (int d = 0; d < 3; ++d) vol *= std::max(0.05, (double)mx[d] - (double)mn[d]);
     hh = std::cbrt(vol / (double)n) * 1.5;  // first guess; refined from measured occupancy below
     hh = std::max(hh, 0.02);
+    // consecutive scans / submaps look alike: start from the voxel the last cloud of similar size ended with
+    // (saves the refinement passes, each a histogram + scan + host read-back)
+    for (const auto& e : h->voxel_memo)
+      if (e.second > 0.0 && (double)n > 0.5 * (double)e.first && (double)n < 2.0 * (double)e.first) hh = e.second;
   }
   dc->grid = make_grid(mn, mx, hh, max_cells);
   unsigned long long occ = 0;
@@ -289,6 +294,11 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
       dc->grid = make_grid(mn, mx, hh, max_cells);
       count_and_scan(h, *dc, ni, &occ);
     }
+  }
+  if (auto_h) {  // remember the voxel for the next cloud of this size class (two entries: scan-sized and submap-sized)
+    int slot = 0;
+    if (h->voxel_memo[0].second > 0.0 && !((double)n > 0.5 * (double)h->voxel_memo[0].first && (double)n < 2.0 * (double)h->voxel_memo[0].first)) slot = 1;
+    h->voxel_memo[slot] = {n, (double)dc->grid.h};
   }
   const Grid& g = dc->grid;
   h->fill.ensure((size_t)(g.ncells + 1) * sizeof(int));
