@@ -304,66 +304,46 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
   if (e <= s) return;
   gsteps += 0x10000u;
   m = min(max(m, s), e - 1);
-  // first round trip: the 8 points around the start.  Most walks end here: both neighbours of the window are ruled out by
-  // their x-gap alone.
-  bool go_right, go_left;
-  {
+  // ONE loop body serves the three kinds of step (the 8 points around the start, then 8 more to the right while that side is
+  // alive, then to the left): a window [w, w + 8) of the run, always read in increasing position, so that c[0] / c[7] are its
+  // smallest / largest x and, among equal distances, the first one met has the smallest position (strict `<` below).
+  // Most walks end after the first window: both neighbours are ruled out by their x-gap alone.
+  int w = m - 4, dir = 0, lo = m - 4, hi = m + 4;  // [lo, hi) has been read
+  bool go_left = false;
+  for (;;) {
     float4 c[8];
     int idx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      idx[j] = min(max(m - 4 + j, s), e - 1);
+      idx[j] = min(max(w + j, s), e - 1);  // clamped duplicates can never win (same distance AND same position)
       c[j] = tgt[idx[j]];
     }
+    float lb = sqdist(qx, qy, qz, c[0]);
+    int lp = idx[0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 1; j < 8; ++j) {
       const float d = sqdist(qx, qy, qz, c[j]);
-      if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
+      if (d < lb) { lb = d; lp = idx[j]; }
     }
+    if (nn_better(lb, lp, best, pos)) { best = lb; pos = lp; }
     ncand += 8;
     ++gsteps;
     const float lim = fminf(best, gate_sq), dr = c[7].x - qx, dl = qx - c[0].x;
-    go_right = m + 4 < e && !(dr > 0.f && dr * dr + gyz > lim);
-    go_left = m - 5 >= s && !(dl > 0.f && dl * dl + gyz > lim);
+    const bool more_right = hi < e && !(dr > 0.f && dr * dr + gyz > lim);
+    const bool more_left = lo > s && !(dl > 0.f && dl * dl + gyz > lim);
+    if (dir == 0) go_left = more_left;
+    if (dir >= 0 && more_right) {
+      dir = 1;
+      w = hi;
+      hi += 8;
+    } else if (dir >= 0 ? go_left : more_left) {
+      dir = -1;
+      lo -= 8;
+      w = lo;
+    } else {
+      break;
+    }
   }
-  if (go_right)
-    for (int p = m + 4; p < e; p += 8) {  // rightwards, 8 loads in flight
-      float4 c[8];
-      int idx[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        idx[j] = min(p + j, e - 1);
-        c[j] = tgt[idx[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = sqdist(qx, qy, qz, c[j]);
-        if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
-      }
-      ncand += 8;
-      ++gsteps;
-      const float dx = c[7].x - qx;
-      if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
-    }
-  if (go_left)
-    for (int p = m - 5; p >= s; p -= 8) {  // leftwards
-      float4 c[8];
-      int idx[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        idx[j] = max(p - j, s);
-        c[j] = tgt[idx[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = sqdist(qx, qy, qz, c[j]);
-        if (nn_better(d, idx[j], best, pos)) { best = d; pos = idx[j]; }
-      }
-      ncand += 8;
-      ++gsteps;
-      const float dx = qx - c[7].x;
-      if (dx > 0.f && dx * dx + gyz > fminf(best, gate_sq)) break;
-    }
 }
 
 #define NG_STAMP(k)                                                                                   \
