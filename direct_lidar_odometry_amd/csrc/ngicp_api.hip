@@ -76,7 +76,9 @@ struct DevBuf {
 // source/target slots (swapSourceAndTarget) through shared_ptr.
 struct DeviceCloud {
   size_t n = 0;
-  DevBuf sorted;      // float4[n]
+  DevBuf sorted;      // float4[kSortedPad + n + kSortedPad]: the cell-sorted points between two runs of far-away sentinels, so
+                      // that the 8-point windows of the search may overhang the array's ends without index clamps
+  float4* pts() const { return sorted.as<float4>() + kSortedPad; }
   DevBuf perm;        // int[n]    sorted position -> original index
   DevBuf inv_perm;    // int[n]    original index -> sorted position (lazily built)
   bool has_inv = false;
@@ -303,11 +305,12 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
   const Grid& g = dc->grid;
   h->fill.ensure((size_t)(g.ncells + 1) * sizeof(int));
   HIP_TRY(hipMemsetAsync(h->fill.p, 0, (size_t)(g.ncells + 1) * sizeof(int), h->stream));
-  dc->sorted.ensure(n * sizeof(float4));
+  dc->sorted.ensure((n + 2 * kSortedPad) * sizeof(float4));
+  hipLaunchKernelGGL(k_fill_sentinels, dim3(1), dim3(2 * kSortedPad), 0, h->stream, dc->sorted.as<float4>(), ni);
   dc->perm.ensure(n * sizeof(int));
   hipLaunchKernelGGL(k_cell_scatter, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), h->keys.as<int>(), ni, dc->cell_start.as<int>(),
                      h->fill.as<int>(), h->tmp.as<float4>());
-  hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cell_start.as<int>(), dc->sorted.as<float4>(),
+  hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cell_start.as<int>(), dc->pts(),
                      dc->perm.as<int>());
   {
     // query order (Morton over tiles of 2^shift cells; <= 128 tiles per axis => <= 2M histogram bins)
@@ -319,7 +322,7 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
     h->counts.ensure((size_t)(nbins + 1) * sizeof(int));
     h->fill.ensure((size_t)(nbins + 1) * sizeof(int));  // reused as tile_start
     HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(nbins + 1) * sizeof(int), h->stream));
-    hipLaunchKernelGGL(k_tile_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni, g, shift, h->counts.as<int>());
+    hipLaunchKernelGGL(k_tile_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, h->counts.as<int>());
     const int ntiles = (nbins + kScanTile - 1) / kScanTile;
     h->tile_sums.ensure((size_t)ntiles * sizeof(int));
     hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), (unsigned long long*)nullptr);
@@ -327,7 +330,7 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
                        (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), h->fill.as<int>());
     dc->qpts.ensure(n * sizeof(float4));
-    hipLaunchKernelGGL(k_tile_place, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni, g, shift, dc->cell_start.as<int>(),
+    hipLaunchKernelGGL(k_tile_place, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, dc->cell_start.as<int>(),
                        h->fill.as<int>(), dc->qpts.as<float4>());
     // tile-aligned query batches
     h->keys.ensure((size_t)(nbins + 1) * sizeof(int));   // batches per tile
@@ -375,7 +378,7 @@ void ensure_slot_ready(ngicp* h, Slot& s, const char* what) {
 // ------------------------------------------------------------------------------------------
 template <int K>
 void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out) {
-  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + 127) / 128)), dim3(128), 0, h->stream, dc.sorted.as<float4>(), dc.cell_start.as<int>(), dc.grid, (int)dc.n, k,
+  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + 127) / 128)), dim3(128), 0, h->stream, dc.pts(), dc.cell_start.as<int>(), dc.grid, (int)dc.n, k,
                      reg, out);
 }
 
@@ -514,7 +517,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.n_batches = S.n_batches;
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
   a.n_src = (int)n;
-  a.tgt = T.sorted.as<float4>();
+  a.tgt = T.pts();
   a.tgt_cell_start = T.cell_start.as<int>();
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
@@ -686,7 +689,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     h->tfinal.ensure(16 * sizeof(float));
     h->out_xyz.ensure(n * 3 * sizeof(float));
     HIP_TRY(hipMemcpyAsync(h->tfinal.p, h->final_T, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_transform_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->src.dev->sorted.as<float4>(), (int)n, h->tfinal.as<float>(),
+    hipLaunchKernelGGL(k_transform_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->src.dev->pts(), (int)n, h->tfinal.as<float>(),
                        h->out_xyz.as<float>());
     if (out_stride == 12) {
       HIP_TRY(hipMemcpyAsync(aligned, h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
@@ -1073,7 +1076,7 @@ int ngicp_get_correspondences(ngicp_t* h, int* corr_out, float* sqd_out) {
     h->knn_d2.ensure(n * sizeof(float));
     LmState* dst = h->state.as<LmState>();
     hipLaunchKernelGGL(k_corr_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->corr[st.hot.cur].as<int>(), h->src.dev->qpts.as<float4>(),
-                       h->src.dev->sorted.as<float4>(), h->tgt.dev->sorted.as<float4>(), (int)n, h->knn_idx.as<int>(), sqd_out ? h->knn_d2.as<float>() : nullptr, dst->xi_f);
+                       h->src.dev->pts(), h->tgt.dev->pts(), (int)n, h->knn_idx.as<int>(), sqd_out ? h->knn_d2.as<float>() : nullptr, dst->xi_f);
     HIP_TRY(hipMemcpyAsync(corr_out, h->knn_idx.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (sqd_out) HIP_TRY(hipMemcpyAsync(sqd_out, h->knn_d2.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1104,13 +1107,13 @@ int ngicp_target_knn(ngicp_t* h, const float* q, size_t nq, size_t stride, int k
     HIP_TRY(hipMemcpyAsync(h->queries.p, packed.data(), nq * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     const dim3 grid((unsigned)((nq + 127) / 128)), block(128);
     if (k <= 10)
-      hipLaunchKernelGGL(k_knn_queries<10>, grid, block, 0, h->stream, T.sorted.as<float4>(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+      hipLaunchKernelGGL(k_knn_queries<10>, grid, block, 0, h->stream, T.pts(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());
     else if (k <= 20)
-      hipLaunchKernelGGL(k_knn_queries<20>, grid, block, 0, h->stream, T.sorted.as<float4>(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+      hipLaunchKernelGGL(k_knn_queries<20>, grid, block, 0, h->stream, T.pts(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());
     else
-      hipLaunchKernelGGL(k_knn_queries<32>, grid, block, 0, h->stream, T.sorted.as<float4>(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+      hipLaunchKernelGGL(k_knn_queries<32>, grid, block, 0, h->stream, T.pts(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());
     HIP_TRY(hipMemcpyAsync(idx, h->knn_idx.p, nq * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(d2, h->knn_d2.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));

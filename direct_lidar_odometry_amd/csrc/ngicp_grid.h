@@ -322,6 +322,14 @@ __global__ void __launch_bounds__(256) k_tile_place(const float4* __restrict__ s
   }
 }
 
+// The cell-sorted point array is framed by kSortedPad far-away sentinels on each side (see DeviceCloud::sorted).
+constexpr int kSortedPad = 8;
+__global__ void k_fill_sentinels(float4* __restrict__ padded, int n) {
+  const int t = threadIdx.x;  // 2 * kSortedPad threads
+  const float far = 3.0e38f;  // squared distance overflows to +inf: never closer than anything
+  padded[t < kSortedPad ? t : n + t] = make_float4(far, far, far, __int_as_float(-1));
+}
+
 // Query batches: runs of at most kBatchQueries consecutive entries of qpts that never cross a tile
 // boundary, so a batch's bounding box is at most one tile.  batch[b] = {first qpts index, count}.
 constexpr int kBatchQueries = 32;

@@ -311,21 +311,21 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
   int w = m - 4, dir = 0, lo = m - 4, hi = m + 4;  // [lo, hi) has been read
   bool go_left = false;
   for (;;) {
+    // No index clamps: a window that overhangs [s, e) reads points of the neighbouring runs (genuine target points: they can
+    // only be legitimate candidates) or the sentinels that frame the array (infinitely far).  The x-gap tests below only
+    // look at c[7] / c[0] when the window's right / left end is inside the run.
+    const float4* __restrict__ q = tgt + w;  // one address, immediate offsets
     float4 c[8];
-    int idx[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      idx[j] = min(max(w + j, s), e - 1);  // clamped duplicates can never win (same distance AND same position)
-      c[j] = tgt[idx[j]];
-    }
+    for (int j = 0; j < 8; ++j) c[j] = q[j];
     float lb = sqdist(qx, qy, qz, c[0]);
-    int lp = idx[0];
+    int lj = 0;
 #pragma unroll
     for (int j = 1; j < 8; ++j) {
       const float d = sqdist(qx, qy, qz, c[j]);
-      if (d < lb) { lb = d; lp = idx[j]; }
+      if (d < lb) { lb = d; lj = j; }
     }
-    if (nn_better(lb, lp, best, pos)) { best = lb; pos = lp; }
+    if (nn_better(lb, w + lj, best, pos)) { best = lb; pos = w + lj; }
     ncand += 8;
     ++gsteps;
     const float lim = fminf(best, gate_sq), dr = c[7].x - qx, dl = qx - c[0].x;
