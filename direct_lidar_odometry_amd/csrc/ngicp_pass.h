@@ -872,6 +872,10 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
   if (a.mode == 0 && st->hot.done) return;
+  // the state the serial lane will work on: fetched now by the whole block (one coalesced round trip that overlaps the
+  // partial loads) instead of by lane 0 after the reduction, where it would be a dependent round trip on the critical path
+  __shared__ int hot_copy[(sizeof(LmHot) + 3) / 4];
+  for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) hot_copy[w] = reinterpret_cast<const int*>(&st->hot)[w];
   const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
   if (order_it)  // the groups' measured costs, for the launch order built further down (visible after the barriers below)
     for (int gi = threadIdx.x; gi < a.nblocks; gi += kSolveThreads) ord_cost[gi] = a.grp_cost[gi];
@@ -956,7 +960,12 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   }
   if (threadIdx.x != 0) return;
 
-  LmHot L = st->hot;  // private register copy
+  LmHot L;  // private register copy
+  {
+    int* dstw = reinterpret_cast<int*>(&L);
+#pragma unroll
+    for (int w = 0; w < (int)(sizeof(LmHot) / 4); ++w) dstw[w] = hot_copy[w];
+  }
   if (a.mode == 1) {  // linearize hook
     adopt_new(L, sums);
     st->hot = L;
