@@ -269,6 +269,11 @@ constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
 constexpr int kStageXs = 20;         // cells per row of the staged region
 constexpr int kStageMaxGrow = 6;
 
+#ifndef NGICP_WALK_WINDOW
+#define NGICP_WALK_WINDOW 12
+#endif
+constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
+
 struct WaveStage {
   union {
     struct {
@@ -299,6 +304,7 @@ __device__ __forceinline__ float row_gap_sq(const Grid& g, int ry, int rz, int c
 // x-gap alone rules the rest out.  Any start is correct (a side only stops once it is past qx AND out of reach); a good
 // start (interpolated from the cell geometry: points of a dense scan line are nearly equidistant in x) makes the cost
 // O(points within reach) with no search at all.  This is what keeps dense scan lines affordable.
+template <int W = kWalkWindow>
 __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
                                                     float& best, int& pos, unsigned int& ncand, unsigned int& gsteps) {
   if (e <= s) return;
@@ -308,37 +314,37 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
   // alive, then to the left): a window [w, w + 8) of the run, always read in increasing position, so that c[0] / c[7] are its
   // smallest / largest x and, among equal distances, the first one met has the smallest position (strict `<` below).
   // Most walks end after the first window: both neighbours are ruled out by their x-gap alone.
-  int w = m - 4, dir = 0, lo = m - 4, hi = m + 4;  // [lo, hi) has been read
+  int w = m - W / 2, dir = 0, lo = m - W / 2, hi = m - W / 2 + W;  // [lo, hi) has been read
   bool go_left = false;
   for (;;) {
     // No index clamps: a window that overhangs [s, e) reads points of the neighbouring runs (genuine target points: they can
     // only be legitimate candidates) or the sentinels that frame the array (infinitely far).  The x-gap tests below only
     // look at c[7] / c[0] when the window's right / left end is inside the run.
     const float4* __restrict__ q = tgt + w;  // one address, immediate offsets
-    float4 c[8];
+    float4 c[W];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = q[j];
+    for (int j = 0; j < W; ++j) c[j] = q[j];
     float lb = sqdist(qx, qy, qz, c[0]);
     int lj = 0;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < W; ++j) {
       const float d = sqdist(qx, qy, qz, c[j]);
       if (d < lb) { lb = d; lj = j; }
     }
     if (nn_better(lb, w + lj, best, pos)) { best = lb; pos = w + lj; }
-    ncand += 8;
+    ncand += W;
     ++gsteps;
-    const float lim = fminf(best, gate_sq), dr = c[7].x - qx, dl = qx - c[0].x;
+    const float lim = fminf(best, gate_sq), dr = c[W - 1].x - qx, dl = qx - c[0].x;
     const bool more_right = hi < e && !(dr > 0.f && dr * dr + gyz > lim);
     const bool more_left = lo > s && !(dl > 0.f && dl * dl + gyz > lim);
     if (dir == 0) go_left = more_left;
     if (dir >= 0 && more_right) {
       dir = 1;
       w = hi;
-      hi += 8;
+      hi += W;
     } else if (dir >= 0 ? go_left : more_left) {
       dir = -1;
-      lo -= 8;
+      lo -= W;
       w = lo;
     } else {
       break;

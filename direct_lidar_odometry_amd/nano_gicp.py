@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libngicp_hip.so")
+_LIB_PATH = os.environ.get("NGICP_LIB") or os.path.join(_HERE, "libngicp_hip.so")  # NGICP_LIB: another build of the same HIP library (tuning experiments)
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)
