@@ -60,15 +60,21 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const floa
   return r;
 }
 
-// scan one contiguous run of sorted points
+// scan one contiguous run of sorted points, eight loads in flight per round trip (one load at a time made the covariance
+// kernel purely latency-bound: ~650 dependent round trips per point).  The tail of the run repeats its last point; a repeat
+// is never inserted (j-th candidate only counts while p + j < e).
 template <int K>
 __device__ __forceinline__ void scan_run(const float4* __restrict__ sorted, int s, int e, float qx, float qy, float qz, int k, TopK<K>& top, float& worst) {
-  for (int p = s; p < e; ++p) {
-    const float4 c = sorted[p];
-    const float d = sqdist(qx, qy, qz, c);
-    if (d < worst) {
-      top.insert(d, p);
-      worst = top.kth(k);
+  for (int p = s; p < e; p += 8) {
+    float d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = sqdist(qx, qy, qz, sorted[min(p + j, e - 1)]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (p + j < e && d[j] < worst) {
+        top.insert(d[j], p + j);
+        worst = top.kth(k);
+      }
     }
   }
 }
