@@ -155,6 +155,8 @@ struct ngicp {
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
   DevBuf dbg, grp_order, grp_cost;
+  const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
+  int order_groups = -1;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
@@ -619,6 +621,10 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   prepare_loop(h, c);
   LmState st;
   init_state_from_pose(st, pose_from_colmajor_f(guess));
+  // the launch order the previous align ended with is still a good guess when the source index is the same one
+  // (same batches; the costs come mostly from where the batches lie): the first pass then starts sorted as well
+  st.order_valid = (h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks) ? 1 : 0;
+  h->order_src = nullptr;  // set again below, once this align has left a complete order behind
   c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
   if (const char* dbg = std::getenv("NGICP_DEBUG_MODE")) c.pa.mode |= (std::atoi(dbg) & (8 | 16));  // timing experiments only
   if (h->p.max_iter <= 0) st.hot.done = 1;
@@ -709,6 +715,10 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   }
   ngicp_stats& s = h->stats;
   s.loop_ms = loop_ms;
+  if (st.order_valid) {
+    h->order_src = h->src.dev.get();
+    h->order_groups = c.sa.nblocks;
+  }
   s.passes = st.hot.passes;
   s.outer_iterations = st.hot.nr_iterations + 1;
   s.lm_trials = st.hot.n_trace;
