@@ -144,7 +144,7 @@ def main():
 
     for _ in range(args.warmup):
         g.align(w.guess)
-    g.setProfiling(4)  # HIP events around every 4th pass launch (events between kernels cost stream time)
+    g.setProfiling(7)  # HIP events around every 7th pass launch: 3 of the 21 per align (an event between two kernels costs stream time)
     iters_done = 0
     passes = 0
     pass_ms = 0.0

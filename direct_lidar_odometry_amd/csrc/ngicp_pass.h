@@ -27,7 +27,7 @@ namespace ngk {
 
 constexpr int kPartialStride = 32;  // doubles per block partial: 21 H + 6 b + y0 + yi (+3 pad)
 constexpr int kNumSums = 29;
-constexpr int kNumSlots = 32;      // + candidates tested, valid correspondences, queries served from the LDS stage (exact integers carried as doubles)
+constexpr int kNumSlots = 32;      // + candidates tested, valid correspondences, queries served through the LDS row list (exact integers carried as doubles)
 constexpr int kTraceCols = 8;
 
 struct LmConfig {
@@ -52,7 +52,7 @@ struct LmHot {
   double lambda, nu;
   double cand_total;   // sum over passes of target points distance-tested
   double valid_total;  // sum over passes of gated-in correspondences
-  double staged_total; // sum over passes of queries whose rings 0..grow came from the LDS stage
+  double staged_total; // sum over passes of queries served through the LDS row list of their batch region
   int iter;       // outer iteration index i (impl/lsq_registration_impl.hpp:101-102)
   int trial;      // LM trial index
   int have_lin;   // 0 until the first linearisation exists
@@ -92,7 +92,7 @@ struct PassArgs {
   double* partials;         // [kNumSlots][partial_pitch], slot-major
   int partial_pitch;        // >= number of groups
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
-  int stage_grow;           // rings served from the LDS stage (0: none)
+  int stage_grow;           // rings around the batch box that the LDS row list covers (0: no list, search unindexed)
   unsigned long long* dbg_stamps;  // diagnostic build only: [wave][16] s_memtime stamps, or null
 };
 
@@ -213,7 +213,7 @@ __device__ __forceinline__ void nn_shells(const Grid& g, const float4* __restric
   }
 }
 
-// Rings 0..1 straight from global memory (fallback when a batch's region does not fit the LDS stage):
+// Rings 0..1 without a row list (fallback when a batch's region does not fit the row table):
 // rows (fixed y,z; contiguous in x) are dealt round-robin to the G lanes of the group.
 template <int G>
 __device__ __forceinline__ void nn_ring1_global(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
@@ -265,8 +265,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Partial sums are stored per GROUP, slot-major ([slot][group]), so that (a) the solver reads them coalesced and (b)
 // the result does not depend on the order in which the groups are launched - which the solver sorts by measured cost.
 constexpr int kStageRowsPerLane = 4;
-constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows per stage
-constexpr int kStageXs = 20;         // cells per row of the staged region
+constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows of a batch region
+constexpr int kStageXs = 20;         // cells per row of the region
 constexpr int kStageMaxGrow = 6;
 
 #ifndef NGICP_WALK_WINDOW
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       float best = 3.4028234664e38f;
       int pos = -1;
       NG_STAMP(2);
-      // ---- stage the batch's region.  Its bounding box comes from the batch's precomputed AABB pushed through
+      // ---- index the batch's region.  Its bounding box comes from the batch's precomputed AABB pushed through
       //      the trial pose (no cross-lane reduction); a batch never leaves one Morton tile, so it is bounded. ----
       int b0x, b0y, b0z, b1x, b1y, b1z;
       {
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         }
       }
     }
-    // ---- R0: per-batch reduction through LDS (the stage slice is free now): lanes 0..31 hold the tail's sums;
+    // ---- R0: per-batch reduction through LDS (the row tables are idle now): lanes 0..31 hold the tail's sums;
     //      lane l writes row l of a [32][30] tile, lane v then adds column v in fixed order (deterministic).  A butterfly
     //      of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips.
     {
