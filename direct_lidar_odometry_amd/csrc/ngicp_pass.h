@@ -166,53 +166,6 @@ __device__ __forceinline__ void scan_runs_merged(const float4* __restrict__ tgt,
   }
 }
 
-// Outer shells (Chebyshev radius > rdone) straight from global memory; continues from the (best, pos)
-// found in rings 0..rdone until the exactness bound or the distance gate ends the search.  The row bounds of
-// a shell are fetched in chunks of 8 rows before any row is scanned: most shell rows are empty, so a lane
-// pays one memory round trip per chunk instead of two per row.
-template <int G>
-__device__ __forceinline__ void nn_shells(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                          int cx, int cy, int cz, float gate_sq_f, int sub, int rdone, float& best, int& pos, unsigned int& ncand) {
-  const int rmax = max(max(g.nx, g.ny), g.nz);
-  for (int r = rdone;; ++r) {
-    const float bound = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r);
-    if (best <= bound || bound >= gate_sq_f || r >= rmax) break;
-    // shell r + 1: rows t = sub, sub + G, ... of the (2R+1)^2 (y,z) window clipped to the grid
-    const int R = r + 1;
-    const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
-    const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
-    const int xa = max(cx - R, 0), xb = min(cx + R, g.nx - 1);
-    const bool lo = cx - R >= 0, hi = cx + R <= g.nx - 1;
-    const int wy = y1 - y0 + 1;
-    const int nrows = wy * (z1 - z0 + 1);
-    for (int t0 = sub; t0 < nrows; t0 += 8 * G) {
-      int s0[8], e0[8], s1[8], e1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = t0 + u * G;
-        const bool ok = t < nrows;
-        const int z = z0 + (ok ? t : 0) / wy, y = y0 + (ok ? t : 0) % wy;
-        const int row = (z * g.ny + y) * g.nx;
-        const bool face = z == cz - R || z == cz + R || y == cy - R || y == cy + R;
-        // face rows: one run [xa, xb]; interior rows: the two end cells
-        const int a0 = face ? xa : cx - R, a1 = face ? xb + 1 : cx - R + 1;
-        const bool use0 = ok && (face || lo), use1 = ok && !face && hi;
-        s0[u] = use0 ? cell_start[row + a0] : 0;
-        e0[u] = use0 ? cell_start[row + a1] : 0;
-        s1[u] = use1 ? cell_start[row + cx + R] : 0;
-        e1[u] = use1 ? cell_start[row + cx + R + 1] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        ncand += (unsigned)(e0[u] - s0[u]) + (unsigned)(e1[u] - s1[u]);
-        if (e0[u] > s0[u]) scan_run_nn(tgt, s0[u], e0[u], qx, qy, qz, best, pos);
-        if (e1[u] > s1[u]) scan_run_nn(tgt, s1[u], e1[u], qx, qy, qz, best, pos);
-      }
-    }
-    if (G > 1) group_min<G>(best, pos);
-  }
-}
-
 // Rings 0..1 without a row list (fallback when a batch's region does not fit the row table):
 // rows (fixed y,z; contiguous in x) are dealt round-robin to the G lanes of the group.
 template <int G>
@@ -349,6 +302,66 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
     } else {
       break;
     }
+  }
+}
+
+// Outer shells (Chebyshev radius > rdone) without a row list; continues from the (best, pos) found in rings 0..rdone
+// until the exactness bound or the distance gate ends the search.  Rows whose (y,z) gap already exceeds the reach are skipped
+// without a memory access; the bounds of the others are fetched in chunks of 4 rows before any row is walked (most shell
+// rows are empty, so a lane pays one memory round trip per chunk instead of one per row); the walks are x-pruned like
+// everywhere else, so a large distance gate costs O(R^2) rows per shell, not O(R^3) points.
+template <int G>
+__device__ __forceinline__ void nn_shells(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                          int cx, int cy, int cz, float gate_sq_f, int sub, int rdone, float& best, int& pos, unsigned int& ncand) {
+  const int rmax = max(max(g.nx, g.ny), g.nz);
+  unsigned int steps = 0;
+  for (int r = rdone;; ++r) {
+    const float bound = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r);
+    if (best <= bound || bound >= gate_sq_f || r >= rmax) break;
+    // shell r + 1: rows t = sub, sub + G, ... of the (2R+1)^2 (y,z) window clipped to the grid
+    const int R = r + 1;
+    const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+    const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+    const int xa = max(cx - R, 0), xb = min(cx + R, g.nx - 1);
+    const bool lo = cx - R >= 0, hi = cx + R <= g.nx - 1;
+    const int wy = y1 - y0 + 1;
+    const int nrows = wy * (z1 - z0 + 1);
+    const float xfrac = fminf(fmaxf((qx - (g.ox + (float)xa * g.h)) / ((float)(xb + 1 - xa) * g.h), 0.f), 1.f);
+    for (int t0 = sub; t0 < nrows; t0 += 4 * G) {
+      int s0[4], e0[4], s1[4], e1[4];
+      float gap[4];
+      const float lim = fminf(best, gate_sq_f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u * G;
+        const bool ok = t < nrows;
+        const int z = z0 + (ok ? t : 0) / wy, y = y0 + (ok ? t : 0) % wy;
+        const int row = (z * g.ny + y) * g.nx;
+        const bool face = z == cz - R || z == cz + R || y == cy - R || y == cy + R;
+        gap[u] = row_gap_sq(g, y, z, cy, cz, qy, qz);
+        const bool want = ok && gap[u] <= lim;
+        // face rows: one run [xa, xb] (marked by s1 = -1); interior rows: the two end cells
+        const int a0 = face ? xa : cx - R, a1 = face ? xb + 1 : cx - R + 1;
+        const bool use0 = want && (face || lo), use1 = want && !face && hi;
+        s0[u] = use0 ? cell_start[row + a0] : 0;
+        e0[u] = use0 ? cell_start[row + a1] : 0;
+        s1[u] = use1 ? cell_start[row + cx + R] : (face ? -1 : 0);
+        e1[u] = use1 ? cell_start[row + cx + R + 1] : 0;
+      }
+#pragma unroll 1
+      for (int u = 0; u < 4; ++u) {
+        int a0 = s0[0], b0 = e0[0], a1 = s1[0], b1 = e1[0];
+        float gp = gap[0];
+#pragma unroll
+        for (int v = 1; v < 4; ++v)
+          if (u == v) a0 = s0[v], b0 = e0[v], a1 = s1[v], b1 = e1[v], gp = gap[v];
+        if (gp > fminf(best, gate_sq_f)) continue;
+        // a face row starts where qx sits in it; the end cells start at their end nearest to the query
+        if (b0 > a0) scan_global_outward(tgt, a0, b0, a1 < 0 ? a0 + (int)(xfrac * (float)(b0 - a0)) : b0 - 1, qx, qy, qz, gp, gate_sq_f, best, pos, ncand, steps);
+        if (b1 > a1 && a1 >= 0) scan_global_outward(tgt, a1, b1, a1, qx, qy, qz, gp, gate_sq_f, best, pos, ncand, steps);
+      }
+    }
+    if (G > 1) group_min<G>(best, pos);
   }
 }
 
