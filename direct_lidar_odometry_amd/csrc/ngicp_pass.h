@@ -461,6 +461,16 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       }
       float best = 3.4028234664e38f;
       int pos = -1;
+      // Warm start: between two LM trials the pose moves little, so the previous correspondence is almost always still the
+      // nearest neighbour.  It is a genuine target point, so taking it as the first candidate keeps the search exact (the
+      // total order decides as before) - but every row and every window is pruned against a tight bound from the start.
+      if (qok && st->hot.have_lin) {
+        const int jp = corr_old[qi];
+        if (jp >= 0) {
+          best = sqdist(qx, qy, qz, a.tgt[jp]);
+          pos = jp;
+        }
+      }
       NG_STAMP(2);
       // ---- index the batch's region.  Its bounding box comes from the batch's precomputed AABB pushed through
       //      the trial pose (no cross-lane reduction); a batch never leaves one Morton tile, so it is bounded. ----
@@ -565,8 +575,10 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
             if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny && S.row_live[(z - Z0) * wy + (y - Y0)] != 0xffff) {
               const int rowb = (z * g.ny + y) * g.nx;
               r_g[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
-              r_s[k] = a.tgt_cell_start[rowb + cxa];
-              r_e[k] = a.tgt_cell_start[rowb + cxb];
+              if (r_g[k] <= fminf(best, a.gate_sq_f)) {  // with a warm start most neighbour rows are ruled out right here
+                r_s[k] = a.tgt_cell_start[rowb + cxa];
+                r_e[k] = a.tgt_cell_start[rowb + cxb];
+              }
             }
           }
 #pragma unroll
