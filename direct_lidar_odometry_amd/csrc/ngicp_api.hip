@@ -154,7 +154,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
-  DevBuf dbg, grp_order, grp_cost;
+  DevBuf dbg, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
@@ -533,6 +533,8 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
     if ((double)f < a.gate_sq) f = std::nextafter(f, std::numeric_limits<float>::infinity());
     a.gate_sq_f = f;
   }
+  h->batch_far.ensure((size_t)S.n_batches + 16);
+  a.batch_far = h->batch_far.as<unsigned char>();
   a.st = h->state.as<LmState>();
   a.partials = h->partials.as<double>();
   a.partial_pitch = nblocks;

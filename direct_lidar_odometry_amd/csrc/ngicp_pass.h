@@ -88,6 +88,8 @@ struct PassArgs {
   double* mahal[2];         // [n_src][6]
   double gate_sq;           // corr_dist_threshold_^2 (double, impl/nano_gicp_impl.hpp:195)
   float gate_sq_f;          // float upper bound of gate_sq for ring termination
+  unsigned char* batch_far; // [n_batches] 1 if some query of the batch looked beyond its ring 1 in the previous pass: only then
+                            // are the outer rings of the batch region listed (a wrong guess costs time, not exactness)
   LmState* st;
   double* partials;         // [kNumSlots][partial_pitch], slot-major
   int partial_pitch;        // >= number of groups
@@ -492,7 +494,10 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       bool listed = false;
       if (a.stage_grow >= 1) {
         int rows;
-        for (grow = a.stage_grow;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
+        // Most batches never look beyond ring 1 (and a batch that did not in the last pass will hardly do so now: the pose
+        // moves little): list only the rows of ring 1 for them, a quarter of the region.
+        const int grow_top = (!st->hot.have_lin || a.batch_far[batch] != 0) ? a.stage_grow : 1;
+        for (grow = grow_top;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
           X0 = max(b0x - grow, 0);
           Y0 = max(b0y - grow, 0);
           Z0 = max(b0z - grow, 0);
@@ -548,6 +553,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         d[12] = (unsigned long long)qcount;
         d[13] = (unsigned long long)((b1x - b0x + 1) | ((b1y - b0y + 1) << 8) | ((b1z - b0z + 1) << 16));
       }
+      bool went_far = false;
       if (qok) {
         int rdone = 1;  // rings 0..rdone have been searched exhaustively
         // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
@@ -592,6 +598,10 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
           nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
         }
         NG_STAMP(4);
+        {
+          const float b1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
+          went_far = !in_box || !(best <= b1 || b1 >= a.gate_sq_f);
+        }
         const unsigned int dbg_c1 = ncand;
         unsigned int dbg_rows = 0;
         if (in_box && grow >= 2) {
@@ -623,6 +633,10 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
           atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
         }
         nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, rdone, best, pos, ncand);
+      }
+      {
+        const bool any_far = __any(went_far);
+        if (lane == 0) a.batch_far[batch] = any_far ? 1 : 0;
       }
       NG_STAMP(6);
       // hand query g's result to lane g
