@@ -186,7 +186,7 @@ def test_set_get_covariances_roundtrip_and_reorder(ng):
 
 
 # ------------------------------------------------------------------ linearise / error
-@pytest.mark.parametrize("max_corr", [None, 1.0, 0.3])
+@pytest.mark.parametrize("max_corr", [None, 3.0, 1.0, 0.3])
 def test_linearize_and_error_match_oracle(ng, oracle_mod, max_corr):
     w = clouds.scan_to_scan(10_000)
     g, o = _pair(ng, oracle_mod, w.source, w.target, max_corr)
