@@ -160,7 +160,7 @@ struct ngicp {
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
-  int hook_valid = 0;     // linearize hook has produced correspondences
+  int hook_valid = 0;     // 1: the linearize hook has produced correspondences; 2: an align has (indices of its last linearisation)
 
   // results of the last align
   float final_T[16];
@@ -717,6 +717,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   }
   ngicp_stats& s = h->stats;
   s.loop_ms = loop_ms;
+  if (st.hot.have_lin) h->hook_valid = 2;  // ngicp_get_correspondences: the correspondences of the last adopted linearisation
   if (st.order_valid) {
     h->order_src = h->src.dev.get();
     h->order_groups = c.sa.nblocks;
@@ -1052,7 +1053,7 @@ int ngicp_linearize(ngicp_t* h, const double T[16], double H[36], double b[6], d
 int ngicp_compute_error(ngicp_t* h, const double T[16], double* err) {
   return guarded(h, [&] {
     if (!T) throw ArgError{NGICP_ERR_ARG, "null pose"};
-    if (!h->hook_valid) throw ArgError{NGICP_ERR_STATE, "compute_error needs a preceding linearize"};
+    if (h->hook_valid != 1) throw ArgError{NGICP_ERR_STATE, "compute_error needs a preceding linearize"};
     LoopCtx c;
     prepare_loop(h, c);
     // keep cur / have_lin, replace the trial pose
@@ -1080,7 +1081,7 @@ int ngicp_compute_error(ngicp_t* h, const double T[16], double* err) {
 int ngicp_get_correspondences(ngicp_t* h, int* corr_out, float* sqd_out) {
   return guarded(h, [&] {
     if (!corr_out) throw ArgError{NGICP_ERR_ARG, "null output"};
-    if (!h->hook_valid) throw ArgError{NGICP_ERR_STATE, "no correspondences: call ngicp_linearize first"};
+    if (!h->hook_valid) throw ArgError{NGICP_ERR_STATE, "no correspondences: call ngicp_linearize or ngicp_align first"};
     LmState st;
     HIP_TRY(hipMemcpy(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost));
     const size_t n = h->src.dev->n;

@@ -129,7 +129,9 @@ int ngicp_linearize(ngicp_t* h, const double T_colmajor[16], double H_colmajor[3
 /* NanoGICP::compute_error impl/nano_gicp_impl.hpp:273-296 (stale correspondences of the last linearize) */
 int ngicp_compute_error(ngicp_t* h, const double T_colmajor[16], double* err);
 /* correspondences_ / sq_distances_ of the last linearize, mapped back to ORIGINAL source/target
- * point indices (-1 = gated out). sq_dist may be NULL. */
+ * point indices (-1 = gated out). sq_dist may be NULL.  Also valid after ngicp_align: then the indices are those of the
+ * alignment's last linearisation (the reference's correspondences_ after align); sq_dist is only meaningful after
+ * ngicp_linearize. */
 int ngicp_get_correspondences(ngicp_t* h, int* corr_n, float* sq_dist_n_or_null);
 /* exact k-NN of arbitrary query points in the TARGET cloud (KdTreeFLANN::nearestKSearch,
  * include/nano_gicp/nanoflann.hpp:141-152): original target indices + float squared distances, ascending. */

@@ -244,6 +244,21 @@ def test_align_matches_oracle_scan_to_scan(ng, oracle_mod, case):
     assert np.abs(g.getFinalHessian() - o.getFinalHessian()).max() <= 1e-6 * np.abs(o.getFinalHessian()).max()
 
 
+@pytest.mark.parametrize("case", ["dlo_s2s", "dlo_s2m", "gauss_newton"])
+def test_correspondences_after_align_are_exact(ng, oracle_mod, case):
+    """Every pass after the first starts its search warm (previous correspondence) and groups are launched in a measured-cost
+    order: neither may change a single nearest neighbour.  After align() the reference's correspondences_ are those of its
+    last linearisation (impl/nano_gicp_impl.hpp:174-211 called from :219); compare them index for index."""
+    w = clouds.scan_to_scan(10_000)
+    corr = {"dlo_s2s": 1.0, "dlo_s2m": 0.5}.get(case, 1.0)
+    g, o = _pair(ng, oracle_mod, w.source, w.target, corr, **CASES[case])
+    _share_covariances(g, o, oracle_mod, w.source, w.target, CASES[case].get("setCorrespondenceRandomness", 20))
+    g.align(); o.align()
+    assert g.nr_iterations_ == o.nr_iterations and g.nr_iterations_ >= 2  # several warm-started passes happened
+    cg, _ = g.correspondences(); co, _ = o.correspondences()
+    assert np.array_equal(cg, co)
+
+
 def test_align_scan_to_submap_with_supplied_covariances(ng, oracle_mod):
     """Config-3 shape at reduced size: per-keyframe world-frame covariances concatenated (odom.cc:1318-1325,833)."""
     w = clouds.scan_to_submap(6_000, 3)
