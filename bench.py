@@ -120,7 +120,10 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" == RCCL on ROCm
 
     from direct_lidar_odometry_amd import build, clouds, nano_gicp as ng
-    build.build()
+    if rank == 0:
+        build.build()  # no-op when the in-tree library is up to date
+    if world > 1:
+        dist.barrier()  # the other ranks load what rank 0 left
 
     w = build_workload(rank)
     tgt_covs = keyframe_covariances(ng, w)

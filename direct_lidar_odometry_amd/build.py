@@ -37,7 +37,8 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), *FLAGS, *(extra_flags or []), *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+    tmp = f"{LIB}.{os.getpid()}.tmp"  # unique per process: several ranks may find the library stale at the same time
+    cmd = [hipcc(), *FLAGS, *(extra_flags or []), *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -46,7 +47,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
         raise RuntimeError("hipcc failed")
     if verbose and res.stderr:
         sys.stderr.write(res.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 
