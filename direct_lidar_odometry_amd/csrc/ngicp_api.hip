@@ -66,6 +66,11 @@ struct DevBuf {
     HIP_TRY(hipMalloc(&p, want));
     cap = want;
   }
+  bool ensure_grew(size_t bytes) {  // true when the buffer was (re)allocated: its contents are gone
+    const void* before = p;
+    ensure(bytes);
+    return p != before;
+  }
   template <class T>
   T* as() const {
     return reinterpret_cast<T*>(p);
@@ -167,6 +172,7 @@ struct ngicp {
   double final_hessian[36];
   int converged = 0, nr_iterations = 0;
   std::vector<double> trace_host;
+  size_t trace_rows_dev = 0;  // rows of the last align's LM trace still on the device
   ngicp_stats stats{};
 
   // sharded stepping
@@ -507,7 +513,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   h->grp_cost.ensure((size_t)nblocks * sizeof(int));
   h->state.ensure(sizeof(LmState));
   const int max_rows = std::max(1, h->p.max_iter) * std::max(1, h->p.lm_max_iter) + 1;
-  h->trace.ensure((size_t)max_rows * kTraceCols * sizeof(double));
+  if (h->trace.ensure_grew((size_t)max_rows * kTraceCols * sizeof(double))) h->trace_rows_dev = 0;  // an unfetched trace went with the old buffer
   h->sums.ensure(kPartialStride * sizeof(double));
 
   PassArgs& a = c.pa;
@@ -689,8 +695,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   for (int r = 0; r < 6; ++r)
     for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.final_hessian[r * 6 + cc];
   if (st.hot.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // impl/lsq_registration_impl.hpp:106
-  h->trace_host.resize((size_t)st.hot.n_trace * kTraceCols);
-  if (st.hot.n_trace) HIP_TRY(hipMemcpy(h->trace_host.data(), h->trace.p, h->trace_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+  h->trace_host.clear();  // fetched on demand (ngicp_get_lm_trace): a diagnostic should not cost every align a synchronous copy
+  h->trace_rows_dev = (size_t)st.hot.n_trace;
 
   if (aligned) {
     const size_t n = h->src.dev->n;
@@ -1137,6 +1143,10 @@ int ngicp_target_knn(ngicp_t* h, const float* q, size_t nq, size_t stride, int k
 
 int ngicp_get_lm_trace(ngicp_t* h, double* rows, size_t max_rows, size_t* n_rows) {
   return guarded(h, [&] {
+    if (h->trace_host.empty() && h->trace_rows_dev) {
+      h->trace_host.resize(h->trace_rows_dev * kTraceCols);
+      HIP_TRY(hipMemcpy(h->trace_host.data(), h->trace.p, h->trace_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
     const size_t n = h->trace_host.size() / kTraceCols;
     if (n_rows) *n_rows = n;
     if (rows) std::memcpy(rows, h->trace_host.data(), std::min(n, max_rows) * kTraceCols * sizeof(double));
