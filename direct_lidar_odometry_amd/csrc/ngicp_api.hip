@@ -149,6 +149,7 @@ struct ngicp {
   double voxel_size = 0.0;  // 0 = auto
   int lanes_per_query = 0;  // 0 = auto
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
+  int chunk_pairs = 4;      // (pass, solve) pairs enqueued between two polls of the done flag (env NGICP_CHUNK)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
   std::pair<size_t, double> voxel_memo[2] = {{0, 0.0}, {0, 0.0}};  // {cloud size, auto voxel edge} of recent builds
   bool profiling = false;
@@ -645,7 +646,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     c.pa.dbg_stamps = h->dbg.as<unsigned long long>();
   }
   const long max_passes = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? (long)h->p.max_iter : (long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1;
-  const int chunk = 4;
+  int chunk = h->chunk_pairs;
   HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   long launched = 0;
   int slot = 0;
@@ -841,6 +842,7 @@ int ngicp_create(int device, ngicp_t** out) {
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_LANES")) h->lanes_per_query = std::atoi(s);
+    if (const char* s = std::getenv("NGICP_CHUNK")) h->chunk_pairs = std::max(1, std::min(64, std::atoi(s)));
     if (const char* s = std::getenv("NGICP_STAGE_GROW")) h->stage_grow = std::max(0, std::min(kStageMaxGrow, std::atoi(s)));
     *out = h.release();
     return NGICP_OK;
