@@ -217,7 +217,9 @@ Grid make_grid(const float mn[3], const float mx[3], double h, int max_cells) {
   return g;
 }
 
-void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_host /*[1] sum count^2, or null*/) {
+// occ_host: where to put sum(count^2) (synchronous read-back), or null.  occ_device_only: compute it into h->occ but leave it
+// on the device (the caller reads it later, when it synchronises anyway).
+void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_host, bool occ_device_only = false) {
   const Grid& g = dc.grid;
   h->counts.ensure((size_t)(g.ncells + 1) * sizeof(int));
   HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(g.ncells + 1) * sizeof(int), h->stream));
@@ -226,7 +228,7 @@ void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_ho
   h->tile_sums.ensure((size_t)ntiles * sizeof(int));
   h->tile_sq.ensure((size_t)ntiles * sizeof(unsigned long long));
   dc.cell_start.ensure((size_t)(g.ncells + 1) * sizeof(int));
-  unsigned long long* tsq = occ_host ? h->tile_sq.as<unsigned long long>() : nullptr;
+  unsigned long long* tsq = (occ_host || occ_device_only) ? h->tile_sq.as<unsigned long long>() : nullptr;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), g.ncells, h->tile_sums.as<int>(), tsq);
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)tsq,
                      h->occ.as<unsigned long long>());
@@ -278,6 +280,7 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
   const int max_cells = 1 << 25;
   double hh;
   const bool auto_h = !(h->voxel_size > 0.0);
+  bool memo_hit = false;
   if (!auto_h) {
     hh = h->voxel_size;
   } else {
@@ -288,12 +291,17 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
     // consecutive scans / submaps look alike: start from the voxel the last cloud of similar size ended with
     // (saves the refinement passes, each a histogram + scan + host read-back)
     for (const auto& e : h->voxel_memo)
-      if (e.second > 0.0 && (double)n > 0.5 * (double)e.first && (double)n < 2.0 * (double)e.first) hh = e.second;
+      if (e.second > 0.0 && (double)n > 0.5 * (double)e.first && (double)n < 2.0 * (double)e.first) {
+        hh = e.second;
+        memo_hit = true;
+      }
   }
   dc->grid = make_grid(mn, mx, hh, max_cells);
   unsigned long long occ = 0;
-  count_and_scan(h, *dc, ni, auto_h ? &occ : nullptr);
-  if (auto_h) {
+  // with a memoised voxel the occupancy is only checked AFTER the build (it corrects the memo for the next cloud): the
+  // read-back then rides on the build's final synchronisation instead of stalling the pipeline here
+  count_and_scan(h, *dc, ni, (auto_h && !memo_hit) ? &occ : nullptr, auto_h && memo_hit);
+  if (auto_h && !memo_hit) {
     // refine the voxel edge until the mean occupancy seen by a random point (sum c^2 / n) is near the target
     for (int it = 0; it < 4; ++it) {
       const double lam = (double)occ / (double)n;
@@ -305,11 +313,6 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
       dc->grid = make_grid(mn, mx, hh, max_cells);
       count_and_scan(h, *dc, ni, &occ);
     }
-  }
-  if (auto_h) {  // remember the voxel for the next cloud of this size class (two entries: scan-sized and submap-sized)
-    int slot = 0;
-    if (h->voxel_memo[0].second > 0.0 && !((double)n > 0.5 * (double)h->voxel_memo[0].first && (double)n < 2.0 * (double)h->voxel_memo[0].first)) slot = 1;
-    h->voxel_memo[slot] = {n, (double)dc->grid.h};
   }
   const Grid& g = dc->grid;
   h->fill.ensure((size_t)(g.ncells + 1) * sizeof(int));
@@ -358,8 +361,22 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
                        dc->batch_boxes.as<float>());
     HIP_TRY(hipMemcpyAsync(&dc->n_batches, dc->n_batches_dev.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   }
+  // with a memoised voxel the occupancy read-back rides on the build's final synchronisation (it steers the memo for the
+  // next cloud of this size class, not this build)
+  if (auto_h && memo_hit) HIP_TRY(hipMemcpyAsync(&occ, h->occ.p, sizeof(occ), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipEventRecord(h->ev_b, h->stream));
   HIP_TRY(hipEventSynchronize(h->ev_b));
+  if (auto_h) {  // remember the voxel for the next cloud of this size class (two entries: scan-sized and submap-sized)
+    double next_h = (double)dc->grid.h;
+    if (memo_hit) {
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      const double lam = (double)occ / (double)n, ratio = h->target_occupancy / std::max(lam, 1.0);
+      if (!(ratio > 0.75 && ratio < 1.33)) next_h = std::max(0.01, next_h * std::min(4.0, std::max(0.25, std::pow(ratio, 1.0 / 1.5))));
+    }
+    int slot = 0;
+    if (h->voxel_memo[0].second > 0.0 && !((double)n > 0.5 * (double)h->voxel_memo[0].first && (double)n < 2.0 * (double)h->voxel_memo[0].first)) slot = 1;
+    h->voxel_memo[slot] = {n, next_h};
+  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
   dc->build_ms = ms;
