@@ -229,6 +229,8 @@ constexpr int kStageMaxGrow = 6;
 #endif
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
 
+constexpr int kUnitCap = 512;         // queued (query, row) walks per round
+
 struct WaveStage {
   union {
     struct {
@@ -237,6 +239,13 @@ struct WaveStage {
     };
     double red[32 * 30];  // the per-batch reduction reuses the (then idle) tables as scratch
   };
+  // Work distribution inside the wave: a (query, row) walk is a UNIT.  Units are queued here and popped by whichever lane is
+  // free, so a query that needs twenty rows is served by twenty lanes instead of its own two while the lanes of queries that
+  // needed one row would idle.  Results meet in qkey by a 64-bit atomic min on (distance bits, position): the total order.
+  unsigned long long qkey[32];  // per query: nearest so far
+  float4 qtab[32];              // per query: transformed coordinates
+  int units[kUnitCap];          // query | row code << 8
+  int q_tail, q_head;
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -554,86 +563,135 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         d[13] = (unsigned long long)((b1x - b0x + 1) | ((b1y - b0y + 1) << 8) | ((b1z - b0z + 1) << 16));
       }
       bool went_far = false;
-      if (qok) {
-        int rdone = 1;  // rings 0..rdone have been searched exhaustively
-        // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
-        // simply takes the unindexed path
-        const bool in_box = listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
-        unsigned int dbg_g1 = 0, dbg_g2 = 0;
+      // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
+      // simply takes the unindexed path
+      const bool in_box = qok && listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
+      unsigned int dbg_g1 = 0, dbg_g2 = 0;
+      auto pack_key = [](float d, int p) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)p; };
+      if (listed) {  // wave-uniform
+        if (in_box && sub == 0) {
+          ++nstaged;
+          S.qtab[grp] = make_float4(qx, qy, qz, 0.f);
+          S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
+        }
+        if (lane == 0) S.q_tail = 0, S.q_head = 0;
+        wave_lds_sync();
+        // ---- rings 0..1: one unit per non-empty row of the query's 3 x 3 (y,z) window that its (y,z) gap does not rule out ----
         if (in_box) {
-          if (sub == 0) ++nstaged;
-          // ---- rings 0..1: lane `sub` takes rows sub, sub + G, ... of the 3 x 3 (y,z) window, nearest first (own row,
-          //      then the four edge neighbours, then the corners), so that the later rows are pruned by their (y,z) gap
-          //      against a best that is already tight.  A row's three cells are one x-sorted run: the walk starts where
-          //      qx would sit if its points were equidistant and goes outward until the x-gap rules the rest out ----
-          const int cxa = max(cx - 1, 0), cxb = min(cx + 1, g.nx - 1) + 1;
-          const float frac = fminf(fmaxf((qx - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
-          constexpr int NR = (9 + G - 1) / G;
-          int r_s[NR], r_e[NR];
-          float r_g[NR];
-#pragma unroll
-          for (int k = 0; k < NR; ++k) {  // the bounds of all the lane's rows in one round trip
-            const int order = sub + k * G;                          // 0..8 in visiting order
+          const float lim = fminf(best, a.gate_sq_f);
+          for (int order = sub; order < 9; order += G) {
             const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
             const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-            r_s[k] = r_e[k] = 0;
-            r_g[k] = 0.f;
-            if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny && S.row_live[(z - Z0) * wy + (y - Y0)] != 0xffff) {
-              const int rowb = (z * g.ny + y) * g.nx;
-              r_g[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
-              if (r_g[k] <= fminf(best, a.gate_sq_f)) {  // with a warm start most neighbour rows are ruled out right here
-                r_s[k] = a.tgt_cell_start[rowb + cxa];
-                r_e[k] = a.tgt_cell_start[rowb + cxb];
-              }
-            }
+            if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
+            if (S.row_live[(z - Z0) * wy + (y - Y0)] == 0xffff) continue;
+            if (row_gap_sq(g, y, z, cy, cz, qy, qz) > lim) continue;
+            S.units[atomicAdd(&S.q_tail, 1)] = grp | (tt << 8);  // at most 32 x 9 units: fits
           }
-#pragma unroll
-          for (int k = 0; k < NR; ++k) {
-            if (r_e[k] > r_s[k] && r_g[k] <= fminf(best, a.gate_sq_f))
-              scan_global_outward(a.tgt, r_s[k], r_e[k], r_s[k] + (int)(frac * (float)(r_e[k] - r_s[k])), qx, qy, qz, r_g[k], a.gate_sq_f, best, pos, ncand, dbg_g1);
-            if (k == 0 && G > 1) group_min<G>(best, pos);  // both lanes continue from the better of the two nearest rows
-          }
-          if (G > 1) group_min<G>(best, pos);
-        } else {
-          nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
         }
-        NG_STAMP(4);
+        wave_lds_sync();
         {
-          const float b1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-          went_far = !in_box || !(best <= b1 || b1 >= a.gate_sq_f);
+          const int tail = S.q_tail;
+          for (;;) {
+            const int u = atomicAdd(&S.q_head, 1);
+            if (u >= tail) break;
+            const int unit = S.units[u], qs = unit & 31, tt = unit >> 8;
+            const float4 q = S.qtab[qs];
+            int ux, uy, uz;
+            cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
+            const int z = uz + tt / 3 - 1, y = uy + tt % 3 - 1;
+            const float gyz = row_gap_sq(g, y, z, uy, uz, q.y, q.z);
+            const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
+            float ub = __uint_as_float((unsigned int)(k0 >> 32));
+            int up = (int)(unsigned int)k0;
+            if (gyz > fminf(ub, a.gate_sq_f)) continue;
+            const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1, rowb = (z * g.ny + y) * g.nx;
+            const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
+            if (e0 <= s0) continue;
+            const float frac = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+            scan_global_outward(a.tgt, s0, e0, s0 + (int)(frac * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+            atomicMin(&S.qkey[qs], pack_key(ub, up));
+          }
         }
-        const unsigned int dbg_c1 = ncand;
-        unsigned int dbg_rows = 0;
-        if (in_box && grow >= 2) {
-          // ---- rings 2..grow: the listed rows (nearest ring first) that can still hold a closer point ----
-          const float bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-          if (!(best <= bound1 || bound1 >= a.gate_sq_f)) {
-            const int cxa = max(cx - 1, 0), cxb = min(cx + 1, g.nx - 1) + 1;
-            const float frac3 = fminf(fmaxf((qx - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
-            for (int li = sub; li < nlive; li += G) {
+        wave_lds_sync();
+        if (in_box) {
+          const unsigned long long k1 = S.qkey[grp];
+          best = __uint_as_float((unsigned int)(k1 >> 32));
+          pos = (int)(unsigned int)k1;
+        }
+      }
+      if (qok && !in_box) nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
+      NG_STAMP(4);
+      float bound1 = 0.f;
+      if (qok) {
+        bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
+        went_far = !in_box || !(best <= bound1 || bound1 >= a.gate_sq_f);
+      }
+      const unsigned int dbg_c1 = ncand;
+      unsigned int dbg_rows = 0;
+      // ---- rings 2..grow: units for the listed rows (nearest ring first) that can still hold a closer point, in rounds of
+      //      kUnitCap; between rounds every query picks up what its units found, which prunes its remaining rows ----
+      const bool need_far = in_box && grow >= 2 && went_far;
+      if (listed && grow >= 2 && __any(need_far)) {  // wave-uniform
+        int li = sub;
+        bool more = need_far;
+        for (;;) {
+          if (lane == 0) S.q_tail = 0, S.q_head = 0;
+          wave_lds_sync();
+          if (more) {
+            const float lim = fminf(best, a.gate_sq_f);
+            for (; li < nlive; li += G) {
               const int4 rec = S.live[li];
-              // lower bound of the distance from q to anything in row (ry, rz): the (y,z) gap to its cells
-              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz);
-              if (gyz > fminf(best, a.gate_sq_f)) continue;
+              if (row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz) > lim) continue;
+              const int slot = atomicAdd(&S.q_tail, 1);
+              if (slot >= kUnitCap) break;  // this row waits for the next round
+              S.units[slot] = grp | (li << 8);
               ++dbg_rows;
+            }
+            more = li < nlive;
+          }
+          wave_lds_sync();
+          {
+            const int tail = min(S.q_tail, kUnitCap);
+            for (;;) {
+              const int u = atomicAdd(&S.q_head, 1);
+              if (u >= tail) break;
+              const int unit = S.units[u], qs = unit & 31;
+              const int4 rec = S.live[unit >> 8];
+              const float4 q = S.qtab[qs];
+              int ux, uy, uz;
+              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
+              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, uy, uz, q.y, q.z);
+              const unsigned long long k0 = S.qkey[qs];
+              float ub = __uint_as_float((unsigned int)(k0 >> 32));
+              int up = (int)(unsigned int)k0;
+              if (gyz > fminf(ub, a.gate_sq_f)) continue;
               // start where qx sits among the row's three centre cells (one extra round trip, but a much better start
               // than interpolating over the whole region row: the walk is over the whole row either way)
+              const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1;
               const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
               const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
-              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), qx, qy, qz, gyz, a.gate_sq_f, best, pos, ncand, dbg_g2);
+              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              atomicMin(&S.qkey[qs], pack_key(ub, up));
             }
-            if (G > 1) group_min<G>(best, pos);
-            rdone = grow;
           }
+          wave_lds_sync();
+          if (in_box) {
+            const unsigned long long k1 = S.qkey[grp];
+            best = __uint_as_float((unsigned int)(k1 >> 32));
+            pos = (int)(unsigned int)k1;
+          }
+          if (!__any(more)) break;
         }
-        NG_STAMP(5);
-        if (a.dbg_stamps) {
-          unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
-          atomicMax(&d[14], ((unsigned long long)(dbg_g2 & 0xffff) << 48) | ((unsigned long long)(dbg_g2 >> 16) << 32) | ((unsigned long long)dbg_rows << 16) | (ncand - dbg_c1));
-          atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
-        }
-        nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, rdone, best, pos, ncand);
       }
+      NG_STAMP(5);
+      if (a.dbg_stamps && qok) {
+        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
+        atomicMax(&d[14], ((unsigned long long)(dbg_g2 & 0xffff) << 48) | ((unsigned long long)(dbg_g2 >> 16) << 32) | ((unsigned long long)dbg_rows << 16) | (ncand - dbg_c1));
+        atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
+      }
+      // whatever lies beyond the listed rings: rare, per query
+      if (qok) nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, need_far ? grow : 1, best, pos, ncand);
       {
         const bool any_far = __any(went_far);
         if (lane == 0) a.batch_far[batch] = any_far ? 1 : 0;
