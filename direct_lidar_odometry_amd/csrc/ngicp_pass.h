@@ -206,11 +206,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 //            row table (up to the number that covers the distance gate) and fetches, in ONE round trip, the bounds
 //            of every (y,z) row of that region in the cell-sorted target (a row is one contiguous, x-sorted run).
 //            The NON-EMPTY rows go into an LDS list, nearest ring first: empty space costs nothing afterwards;
-//   search   2 lanes per query.  Ring 1: the bounds of the query's (up to 9) window rows come in one round trip, the
-//            rows are walked nearest first.  A walk starts where qx sits in the run (interpolated), fetches the 8
-//            points around it, and continues right / left, 8 points per round trip, only while the x-gap alone does
-//            not rule the rest out.  A query that is not provably exact after ring 1 walks the listed rows that can
-//            still hold a closer point ((y,z)-gap pruning); rings beyond the list use the global shell walk;
+//   search   2 lanes per query set it up (transform, cell, warm start from the previous correspondence).  Every (query, row)
+//            pair that the (y,z)-gap test does not rule out becomes a UNIT in an LDS queue; whichever lane is free pops the
+//            next unit and walks that row: the bounds of the row's cells around qx, then 12-point windows from where qx sits
+//            (interpolated) outward, right / left, only while the x-gap alone does not rule the rest out.  Results meet in a
+//            per-query 64-bit LDS atomic min on (distance bits, position).  Ring 1 (the 3 x 3 window rows) first; a query that
+//            is not provably exact after it queues the listed rows that can still hold a closer point; rings beyond the list
+//            use the per-query shell walk;
 //   tail     lanes 0..31, one query each, FP64: K4 error under the previous correspondences, gate, Mahalanobis,
 //            residual / Jacobian / normal equations.  Its operands were requested before the search.
 // Target points are NOT staged in LDS: measured on MI355X, copying a region's rows (LDS-DMA, 640 points per wave) cost
