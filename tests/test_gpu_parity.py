@@ -205,6 +205,50 @@ def test_linearize_and_error_match_oracle(ng, oracle_mod, max_corr):
         assert abs(g.compute_error(T2) - o.compute_error(T2)) <= 1e-10 * o.compute_error(T2)
 
 
+@pytest.mark.parametrize("shape", ["cube", "plane", "lines", "clumps"])
+def test_correspondences_exact_on_adversarial_shapes(ng, oracle_mod, shape):
+    """The search is exact by construction (total order, conservative bounds); this hammers its corner cases with target
+    geometries unlike a LiDAR scan: uniform volume, one dense plane, dense lines along x / y / z (long x-sorted rows, rows
+    whose points share one x), tight clumps (cells with hundreds of points next to empty space), at several poses and gates.
+    1-NN ties between equidistant points are excluded from the index comparison (kd-tree visiting order)."""
+    rng = np.random.default_rng({"cube": 1, "plane": 2, "lines": 3, "clumps": 4}[shape])
+    n = 6000
+    if shape == "cube":
+        tgt = rng.uniform(-3, 3, (n, 3))
+    elif shape == "plane":
+        tgt = np.c_[rng.uniform(-4, 4, (n, 2)), 0.002 * rng.standard_normal(n)]
+    elif shape == "lines":
+        t = rng.uniform(-4, 4, n); k = rng.integers(0, 3, n); off = rng.integers(-3, 4, (n, 2)) * 0.5
+        tgt = np.zeros((n, 3))
+        for ax in range(3):
+            m = k == ax
+            tgt[m, ax] = t[m]
+            tgt[np.ix_(m, [a for a in range(3) if a != ax])] = off[m]
+        tgt += 0.001 * rng.standard_normal((n, 3))
+    else:
+        centres = rng.uniform(-3, 3, (12, 3))
+        tgt = centres[rng.integers(0, 12, n)] + 0.01 * rng.standard_normal((n, 3))
+    tgt = tgt.astype(np.float32)
+    src = (tgt[rng.permutation(n)[:3000]] + rng.normal(0, 0.05, (3000, 3))).astype(np.float32)
+    src = np.r_[src, rng.uniform(-5, 5, (500, 3)).astype(np.float32)]  # and some queries far from everything
+    tree = oracle_mod.OracleTree(tgt)
+    for gate in (None, 2.0, 0.4):
+        g, o = _pair(ng, oracle_mod, src, tgt, gate)
+        covs = np.tile(np.eye(4)[None] * np.array([1, 1, 1, 0])[None, :, None], (1, 1, 1))
+        cs = np.repeat(covs, len(src), 0); ct = np.repeat(covs, len(tgt), 0)
+        for e in (g, o):
+            e.setSourceCovariances(cs); e.setTargetCovariances(ct)
+        for T in (np.eye(4), clouds.make_pose((0.3, -0.2, 0.1), (2, -1, 5)), clouds.make_pose((0.31, -0.2, 0.1), (2, -1, 5.1))):
+            g.linearize(T); o.linearize(T)
+            cg, sg = g.correspondences(); co, so = o.correspondences()
+            q = clouds.transform_points(T, src)
+            _, d2 = tree.knn(q, 2)
+            tie = (d2[:, 1] - d2[:, 0]) <= 1e-5 * np.maximum(d2[:, 1], 1e-12)  # (numpy's transform may round differently)
+            assert np.array_equal(cg >= 0, co >= 0)
+            assert np.array_equal(cg[~tie], co[~tie])
+            assert np.array_equal(sg[cg >= 0], so[co >= 0])  # the distances agree even where a tie picks another point
+
+
 # ------------------------------------------------------------------ full alignment
 CASES = {
     "dlo_s2s": dict(setMaximumIterations=32, setTransformationEpsilon=0.01, setCorrespondenceRandomness=10),   # cfg/params.yaml:54-62
