@@ -50,6 +50,38 @@ def keyframe_covariances(ng, w):
     return np.concatenate(out)
 
 
+def dlo_frame_ms(ng, w, tgt_covs, device, frames=4):
+    """What one LiDAR frame costs with DLO's own settings (cfg/params.yaml:54-71, src/dlo/odom.cc:498-526,803-840): upload +
+    index of the new scan, its covariances (k = 10), scan-to-scan align against the previous scan (32 iterations at most,
+    eps 0.01, gate 1.0 m), then scan-to-submap align against the 500k-point submap (k = 20, gate 0.5 m) on the shared
+    source index and covariances.  Reported next to the headline number; not part of `value`."""
+    s2s, s2m = ng.NanoGICP(device=device), ng.NanoGICP(device=device)
+    for e, k, d in ((s2s, 10, 1.0), (s2m, 20, 0.5)):
+        e.setCorrespondenceRandomness(k); e.setMaxCorrespondenceDistance(d); e.setMaximumIterations(32); e.setTransformationEpsilon(0.01)
+    s2m.setInputTarget(w.target); s2m.setTargetCovariances(tgt_covs)
+    prev = np.ascontiguousarray(w.target[: len(w.source)])  # the first keyframe: a 100k scan a little away from the source
+    s2s.setInputTarget(prev); s2s.calculateTargetCovariances()
+    scans = [np.ascontiguousarray(w.source + np.float32(1e-3 * i)) for i in range(frames + 1)]  # distinct buffers, like new scans
+    out = []
+    for i, scan in enumerate(scans):
+        t0 = time.perf_counter()
+        s2s.setInputSource(scan); s2s.calculateSourceCovariances()
+        t1 = time.perf_counter()
+        s2s.align(w.guess)
+        t2 = time.perf_counter()
+        s2m.registerInputSource(scan); s2m.shareSourceIndexFrom(s2s); s2m.copySourceCovariancesFrom(s2s)
+        s2m.align(w.guess)
+        t3 = time.perf_counter()
+        if i:  # the first frame warms buffers up
+            out.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s2s.stats()["passes"], s2m.stats()["passes"]))
+    a = np.array(out)
+    s2s.close(); s2m.close()
+    return {"frame_ms": float(a[:, :3].sum(1).mean()), "source_upload_index_covariances_ms": float(a[:, 0].mean()),
+            "scan_to_scan_align_ms": float(a[:, 1].mean()), "scan_to_submap_align_ms": float(a[:, 2].mean()),
+            "scan_to_scan_passes": float(a[:, 3].mean()), "scan_to_submap_passes": float(a[:, 4].mean()),
+            "settings": "DLO cfg/params.yaml: s2s k=10 gate 1.0 m, s2m k=20 gate 0.5 m, 32 iterations max, eps 0.01; 100k-point scans, 500k-point submap"}
+
+
 def cpu_baseline(w, tgt_covs, src_covs):
     """CPU oracle (oracle/ = C++/OpenMP restatement of the reference path) on the same clouds: bounded sample."""
     from oracle import oracle as orc
@@ -222,6 +254,11 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "floor_frac_cbar1": (n_src * (12.0 + 100.0 + 52.0 * k4_frac) / (avg_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if avg_pass_ms > 0 else 0.0},
         }
+        if world == 1:
+            try:
+                out["dlo_frame"] = dlo_frame_ms(ng, w, tgt_covs, local_rank)
+            except Exception as exc:  # informative extra, never fatal
+                out["dlo_frame"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             base, T_cpu = cpu_baseline(w, tgt_covs, src_covs)
             out["cpu_baseline"] = base
