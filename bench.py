@@ -59,7 +59,11 @@ def dlo_frame_ms(ng, w, tgt_covs, device, frames=4):
     for e, k, d in ((s2s, 10, 1.0), (s2m, 20, 0.5)):
         e.setCorrespondenceRandomness(k); e.setMaxCorrespondenceDistance(d); e.setMaximumIterations(32); e.setTransformationEpsilon(0.01)
     s2m.setInputTarget(w.target); s2m.setTargetCovariances(tgt_covs)
-    prev = np.ascontiguousarray(w.target[: len(w.source)])  # the first keyframe: a 100k scan a little away from the source
+    # the previous scan: same scene, sensor 0.3 m / 1.5 deg before the current pose, in its own sensor frame (s2s runs with an
+    # identity guess, odom.cc:803)
+    from direct_lidar_odometry_amd import clouds
+    prev_pose = clouds.gt_transform() @ clouds.make_pose((-0.3, 0.05, 0.0), (0.0, 0.0, -1.5))
+    prev = clouds._sensor("vlp16")(clouds.make_scene(), prev_pose, 77, len(w.source))
     s2s.setInputTarget(prev); s2s.calculateTargetCovariances()
     scans = [np.ascontiguousarray(w.source + np.float32(1e-3 * i)) for i in range(frames + 1)]  # distinct buffers, like new scans
     out = []
@@ -67,7 +71,7 @@ def dlo_frame_ms(ng, w, tgt_covs, device, frames=4):
         t0 = time.perf_counter()
         s2s.setInputSource(scan); s2s.calculateSourceCovariances()
         t1 = time.perf_counter()
-        s2s.align(w.guess)
+        s2s.align()
         t2 = time.perf_counter()
         s2m.registerInputSource(scan); s2m.shareSourceIndexFrom(s2s); s2m.copySourceCovariancesFrom(s2s)
         s2m.align(w.guess)
