@@ -77,12 +77,15 @@ def dlo_frame_ms(ng, w, tgt_covs, device, frames=4):
         s2m.align(w.guess)
         t3 = time.perf_counter()
         if i:  # the first frame warms buffers up
-            out.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s2s.stats()["passes"], s2m.stats()["passes"]))
+            out.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s2s.stats()["passes"], s2m.stats()["passes"], s2s.stats()["loop_ms"],
+                        s2m.stats()["loop_ms"], s2m.stats()["align_ms"]))
     a = np.array(out)
     s2s.close(); s2m.close()
     return {"frame_ms": float(a[:, :3].sum(1).mean()), "source_upload_index_covariances_ms": float(a[:, 0].mean()),
             "scan_to_scan_align_ms": float(a[:, 1].mean()), "scan_to_submap_align_ms": float(a[:, 2].mean()),
             "scan_to_scan_passes": float(a[:, 3].mean()), "scan_to_submap_passes": float(a[:, 4].mean()),
+            "scan_to_scan_device_loop_ms": float(a[:, 5].mean()), "scan_to_submap_device_loop_ms": float(a[:, 6].mean()),
+            "scan_to_submap_align_call_ms": float(a[:, 7].mean()),
             "settings": "DLO cfg/params.yaml: s2s k=10 gate 1.0 m, s2m k=20 gate 0.5 m, 32 iterations max, eps 0.01; 100k-point scans, 500k-point submap"}
 
 

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -95,7 +96,50 @@ struct DeviceCloud {
   int n_batches = 0;
   Grid grid{};
   double build_ms = 0.0;
+  int device = 0;
 };
+
+// Index objects are recycled: a LiDAR pipeline builds a new source index per scan, and hipMalloc / hipFree of its nine
+// buffers (both synchronise the device) cost more than building the index.  The last owner hands the object back to a
+// per-process pool; a build takes one of the right device from it and only grows the buffers that are too small.
+struct CloudPool {
+  std::mutex m;
+  std::vector<DeviceCloud*> free_list;
+};
+CloudPool& cloud_pool() {
+  static CloudPool* p = new CloudPool;  // never destroyed: device memory must not be freed after the HIP runtime has shut down
+  return *p;
+}
+std::shared_ptr<DeviceCloud> acquire_cloud(int device) {
+  DeviceCloud* dc = nullptr;
+  {
+    CloudPool& cp = cloud_pool();
+    std::lock_guard<std::mutex> lock(cp.m);
+    for (size_t i = 0; i < cp.free_list.size(); ++i)
+      if (cp.free_list[i]->device == device) {
+        dc = cp.free_list[i];
+        cp.free_list.erase(cp.free_list.begin() + (long)i);
+        break;
+      }
+  }
+  if (dc) {
+    // its previous owners may still have work in flight on their streams that reads the buffers
+    HIP_TRY(hipDeviceSynchronize());
+    dc->n = 0;
+    dc->has_inv = false;
+    dc->n_batches = 0;
+    dc->build_ms = 0.0;
+  } else {
+    dc = new DeviceCloud;
+    dc->device = device;
+  }
+  return std::shared_ptr<DeviceCloud>(dc, [](DeviceCloud* p) {
+    CloudPool& cp = cloud_pool();
+    std::lock_guard<std::mutex> lock(cp.m);
+    if (cp.free_list.size() < 8) cp.free_list.push_back(p);
+    else delete p;
+  });
+}
 
 // Covariances, packed symmetric FP64 [n][6], stored in the sorted order of `order`.
 struct CovSet {
@@ -243,7 +287,7 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
   if (n == 0) throw ArgError{NGICP_ERR_ARG, "empty cloud"};
   if (n > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "cloud too large for int indices"};
   if (stride < 12 || (stride % 4) != 0) throw ArgError{NGICP_ERR_ARG, "stride_bytes must be a multiple of 4 and >= 12"};
-  auto dc = std::make_shared<DeviceCloud>();
+  auto dc = acquire_cloud(h->device);
   dc->n = n;
   const int ni = (int)n;
   const double t0 = now_ms();
