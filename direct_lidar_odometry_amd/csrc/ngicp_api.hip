@@ -110,6 +110,44 @@ CloudPool& cloud_pool() {
   static CloudPool* p = new CloudPool;  // never destroyed: device memory must not be freed after the HIP runtime has shut down
   return *p;
 }
+// the same for covariance sets (one per scan, 48 bytes per point)
+struct BufPool {
+  std::mutex m;
+  std::vector<std::pair<int, DevBuf*>> free_list;  // {device, buffer}
+};
+BufPool& buf_pool() {
+  static BufPool* p = new BufPool;
+  return *p;
+}
+std::shared_ptr<DevBuf> acquire_buf(int device, size_t bytes) {
+  DevBuf* b = nullptr;
+  {
+    BufPool& bp = buf_pool();
+    std::lock_guard<std::mutex> lock(bp.m);
+    size_t best = bp.free_list.size();
+    for (size_t i = 0; i < bp.free_list.size(); ++i)  // best fit: a scan's set must not take the submap's buffer
+      if (bp.free_list[i].first == device && bp.free_list[i].second->cap >= bytes &&
+          (best == bp.free_list.size() || bp.free_list[i].second->cap < bp.free_list[best].second->cap))
+        best = i;
+    if (best < bp.free_list.size()) {
+      b = bp.free_list[best].second;
+      bp.free_list.erase(bp.free_list.begin() + (long)best);
+    }
+  }
+  if (b) {
+    HIP_TRY(hipDeviceSynchronize());  // previous owners' work on other streams
+  } else {
+    b = new DevBuf;
+    b->ensure(bytes);
+  }
+  return std::shared_ptr<DevBuf>(b, [device](DevBuf* p) {
+    BufPool& bp = buf_pool();
+    std::lock_guard<std::mutex> lock(bp.m);
+    if (bp.free_list.size() < 12) bp.free_list.emplace_back(device, p);
+    else delete p;
+  });
+}
+
 std::shared_ptr<DeviceCloud> acquire_cloud(int device) {
   DeviceCloud* dc = nullptr;
   {
@@ -458,8 +496,7 @@ void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
   const int k = h->p.k;
   if (k <= 0) throw ArgError{NGICP_ERR_ARG, "k must be positive"};
   if (k > 32 || (size_t)k > dc.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
-  auto buf = std::make_shared<DevBuf>();
-  buf->ensure(dc.n * 6 * sizeof(double));
+  auto buf = acquire_buf(h->device, dc.n * 6 * sizeof(double));
   HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   const int reg = h->p.regularization;
   if (k <= 10)
@@ -485,8 +522,7 @@ const double* covs_for(ngicp* h, CovSet& cs, const std::shared_ptr<DeviceCloud>&
   // covariances are logically indexed by ORIGINAL point index (the reference's vector index):
   // re-order from the donor cloud's sorted order to this cloud's sorted order
   ensure_inv_perm(h, *cs.order);
-  auto buf = std::make_shared<DevBuf>();
-  buf->ensure(dc->n * 6 * sizeof(double));
+  auto buf = acquire_buf(h->device, dc->n * 6 * sizeof(double));
   hipLaunchKernelGGL(k_covs_reorder, dim3((unsigned)((dc->n + 255) / 256)), dim3(256), 0, h->stream, cs.data->as<double>(), cs.order->inv_perm.as<int>(), dc->perm.as<int>(),
                      (int)dc->n, buf->as<double>());
   cs.data = buf;
@@ -515,8 +551,7 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
   ensure_slot_ready(h, slot, what);
   h->scratch16.ensure(n * 16 * sizeof(double));
   HIP_TRY(hipMemcpyAsync(h->scratch16.p, in, n * 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  auto buf = std::make_shared<DevBuf>();
-  buf->ensure(n * 6 * sizeof(double));
+  auto buf = acquire_buf(h->device, n * 6 * sizeof(double));
   hipLaunchKernelGGL(k_covs_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->scratch16.as<double>(), slot.dev->perm.as<int>(), (int)n, buf->as<double>());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
