@@ -226,6 +226,8 @@ struct ngicp {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_poll[2] = {nullptr, nullptr};
+  hipEvent_t ev_cov_a = nullptr, ev_cov_b = nullptr;  // around the last covariance kernel; read lazily (ngicp_get_stats)
+  bool cov_timing_pending = false;
   std::string err;
   Params p;
   double voxel_size = 0.0;  // 0 = auto
@@ -497,7 +499,7 @@ void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
   if (k <= 0) throw ArgError{NGICP_ERR_ARG, "k must be positive"};
   if (k > 32 || (size_t)k > dc.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
   auto buf = acquire_buf(h->device, dc.n * 6 * sizeof(double));
-  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+  HIP_TRY(hipEventRecord(h->ev_cov_a, h->stream));
   const int reg = h->p.regularization;
   if (k <= 10)
     launch_cov<10>(h, dc, k, reg, buf->as<double>());
@@ -505,12 +507,9 @@ void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
     launch_cov<20>(h, dc, k, reg, buf->as<double>());
   else
     launch_cov<32>(h, dc, k, reg, buf->as<double>());
-  HIP_TRY(hipEventRecord(h->ev_b, h->stream));
-  HIP_TRY(hipEventSynchronize(h->ev_b));
+  HIP_TRY(hipEventRecord(h->ev_cov_b, h->stream));
   HIP_TRY(hipGetLastError());
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
-  h->stats.covariance_ms = ms;
+  h->cov_timing_pending = true;  // no synchronisation here: the covariances are consumed on this same stream
   cs.data = buf;
   cs.n = dc.n;
   cs.order = slot.dev;
@@ -927,6 +926,8 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev_a));
     HIP_TRY(hipEventCreate(&h->ev_b));
+    HIP_TRY(hipEventCreate(&h->ev_cov_a));
+    HIP_TRY(hipEventCreate(&h->ev_cov_b));
     HIP_TRY(hipEventCreate(&h->ev_poll[0]));
     HIP_TRY(hipEventCreate(&h->ev_poll[1]));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_poll), 2 * sizeof(int), hipHostMallocDefault));
@@ -965,6 +966,8 @@ int ngicp_destroy(ngicp_t* h) {
   if (h->h_poll) (void)hipHostFree(h->h_poll);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+  if (h->ev_cov_a) (void)hipEventDestroy(h->ev_cov_a);
+  if (h->ev_cov_b) (void)hipEventDestroy(h->ev_cov_b);
   for (int i = 0; i < 2; ++i)
     if (h->ev_poll[i]) (void)hipEventDestroy(h->ev_poll[i]);
   hipStream_t s = h->stream;
@@ -1253,6 +1256,11 @@ int ngicp_get_lm_trace(ngicp_t* h, double* rows, size_t max_rows, size_t* n_rows
 
 int ngicp_get_stats(ngicp_t* h, ngicp_stats* out) {
   if (!h || !out) return NGICP_ERR_ARG;
+  if (h->cov_timing_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(h->ev_cov_b) == hipSuccess && hipEventElapsedTime(&ms, h->ev_cov_a, h->ev_cov_b) == hipSuccess) h->stats.covariance_ms = ms;
+    h->cov_timing_pending = false;
+  }
   *out = h->stats;
   return NGICP_OK;
 }
