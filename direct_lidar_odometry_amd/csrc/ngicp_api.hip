@@ -250,6 +250,7 @@ struct ngicp {
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
+  LmState* pin_state = nullptr;  // pinned [2]: the state image an align uploads / the one it reads back (no staging copies)
   int hook_valid = 0;     // 1: the linearize hook has produced correspondences; 2: an align has (indices of its last linearisation)
 
   // results of the last align
@@ -732,7 +733,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
   if (const char* dbg = std::getenv("NGICP_DEBUG_MODE")) c.pa.mode |= (std::atoi(dbg) & (8 | 16));  // timing experiments only
   if (h->p.max_iter <= 0) st.hot.done = 1;
-  HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+  h->pin_state[0] = st;
+  HIP_TRY(hipMemcpyAsync(h->state.p, &h->pin_state[0], sizeof(st), hipMemcpyHostToDevice, h->stream));
 
   const char* stamp_path = std::getenv("NGICP_DEBUG_STAMPS");  // diagnostic only
   if (stamp_path) {
@@ -771,9 +773,10 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     slot ^= 1;
   }
   HIP_TRY(hipEventRecord(h->ev_b, h->stream));
-  HIP_TRY(hipMemcpyAsync(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&h->pin_state[1], h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
+  st = h->pin_state[1];
   float loop_ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&loop_ms, h->ev_a, h->ev_b));
 
@@ -932,6 +935,7 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipEventCreate(&h->ev_poll[1]));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_poll), 2 * sizeof(int), hipHostMallocDefault));
     h->h_poll[0] = h->h_poll[1] = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_state), 2 * sizeof(LmState), hipHostMallocDefault));
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(h->final_T, I, sizeof(I));
     std::memset(h->final_hessian, 0, sizeof(h->final_hessian));
@@ -964,6 +968,7 @@ int ngicp_destroy(ngicp_t* h) {
   for (auto& e : h->prof_events)
     if (e) (void)hipEventDestroy(e);
   if (h->h_poll) (void)hipHostFree(h->h_poll);
+  if (h->pin_state) (void)hipHostFree(h->pin_state);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
   if (h->ev_cov_a) (void)hipEventDestroy(h->ev_cov_a);
