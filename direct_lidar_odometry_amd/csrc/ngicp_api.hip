@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ngicp_pass.h"
+#include "ngicp_cloudops.h"
 
 using namespace ngk;
 
@@ -95,6 +96,7 @@ struct DeviceCloud {
   DevBuf batch_boxes; // float[n_batches][6] centre + half extents of each batch (cloud frame)
   int n_batches = 0;
   Grid grid{};
+  float bb_min[3] = {0.f, 0.f, 0.f}, bb_max[3] = {0.f, 0.f, 0.f};  // bounding box of the points (a submap's box is the union of its keyframes')
   double build_ms = 0.0;
   int device = 0;
 };
@@ -263,6 +265,15 @@ struct ngicp {
 
   // sharded stepping
   bool sharded_active = false;
+
+  // device-resident keyframe store (src/dlo/odom.cc keyframes + keyframe_normals) and the submap assembled from it
+  struct Keyframe {
+    std::shared_ptr<DeviceCloud> cloud;  // indexed, cell-sorted
+    std::shared_ptr<DevBuf> covs;        // [n][6] FP64 in the cloud's sorted order
+  };
+  std::vector<Keyframe> keyframes;
+  std::vector<int> submap_ids;           // keyframes of the submap that is the current target (valid while submap_cloud is the target)
+  const DeviceCloud* submap_cloud = nullptr;
 };
 
 namespace {
@@ -324,32 +335,26 @@ void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_ho
   }
 }
 
-std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t n, size_t stride) {
+// Host cloud -> h->unsorted (float4 {x, y, z, bitcast(original index)}) + its bounding box.  The only host read-back of the build
+// (the grid dimensions size the allocations).
+void stage_host_cloud(ngicp* h, const float* xyz, size_t n, size_t stride, float mn[3], float mx[3]) {
   if (n == 0) throw ArgError{NGICP_ERR_ARG, "empty cloud"};
   if (n > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "cloud too large for int indices"};
   if (stride < 12 || (stride % 4) != 0) throw ArgError{NGICP_ERR_ARG, "stride_bytes must be a multiple of 4 and >= 12"};
-  auto dc = acquire_cloud(h->device);
-  dc->n = n;
   const int ni = (int)n;
   const double t0 = now_ms();
   const size_t raw_bytes = (n - 1) * stride + 12;
   h->raw.ensure(raw_bytes);
   HIP_TRY(hipMemcpyAsync(h->raw.p, xyz, raw_bytes, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  h->stats.upload_ms = now_ms() - t0;
-
-  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   h->unsorted.ensure(n * sizeof(float4));
-  h->keys.ensure(n * sizeof(int));
-  h->tmp.ensure(n * sizeof(float4));
   const int bbox_blocks = pick_blocks(n, 1024, 512);
   h->bbox.ensure((size_t)bbox_blocks * 8 * sizeof(float));
-  h->occ.ensure(2 * sizeof(unsigned long long));
   hipLaunchKernelGGL(k_unpack_bbox, dim3(bbox_blocks), dim3(256), 0, h->stream, h->raw.as<unsigned char>(), stride, ni, h->unsorted.as<float4>(), h->bbox.as<float>());
   std::vector<float> bb((size_t)bbox_blocks * 8);
   HIP_TRY(hipMemcpyAsync(bb.data(), h->bbox.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  h->stats.upload_ms = now_ms() - t0;  // copy + unpack + bounding box (one synchronisation)
+  for (int d = 0; d < 3; ++d) mn[d] = 3.0e38f, mx[d] = -3.0e38f;
   float bad = 0.f;
   for (int b = 0; b < bbox_blocks; ++b) {
     for (int d = 0; d < 3; ++d) {
@@ -362,6 +367,18 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
   if (bad > 0.f) throw ArgError{NGICP_ERR_ARG, "cloud contains non-finite coordinates"};
   for (int d = 0; d < 3; ++d)
     if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || mn[d] > mx[d]) throw ArgError{NGICP_ERR_ARG, "cloud contains non-finite coordinates"};
+}
+
+// h->unsorted[0..n) -> an indexed DeviceCloud.  Everything stays on the device; one synchronisation at the end.
+std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3], const float mx[3]) {
+  auto dc = acquire_cloud(h->device);
+  dc->n = n;
+  for (int d = 0; d < 3; ++d) dc->bb_min[d] = mn[d], dc->bb_max[d] = mx[d];
+  const int ni = (int)n;
+  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+  h->keys.ensure(n * sizeof(int));
+  h->tmp.ensure(n * sizeof(float4));
+  h->occ.ensure(2 * sizeof(unsigned long long));
   const int max_cells = 1 << 25;
   double hh;
   const bool auto_h = !(h->voxel_size > 0.0);
@@ -468,6 +485,12 @@ std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t
   h->stats.index_build_ms = ms;
   HIP_TRY(hipGetLastError());
   return dc;
+}
+
+std::shared_ptr<DeviceCloud> upload_and_index(ngicp* h, const float* xyz, size_t n, size_t stride) {
+  float mn[3], mx[3];
+  stage_host_cloud(h, xyz, n, stride, mn, mx);
+  return index_unsorted(h, n, mn, mx);
 }
 
 void ensure_inv_perm(ngicp* h, DeviceCloud& dc) {
@@ -715,6 +738,35 @@ void pose_to_colmajor_f(const Pose& p, float m[16]) {  // x0.cast<float>().matri
   m[15] = 1.f;
 }
 
+// h->out_xyz (packed xyz on the device) -> host xyz at a byte stride
+void download_xyz(ngicp* h, size_t n, float* out, size_t out_stride) {
+  if (out_stride == 12) {
+    HIP_TRY(hipMemcpyAsync(out, h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  } else {
+    std::vector<float> tmp(n * 3);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; ++i) {
+      float* o = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(out) + i * out_stride);
+      o[0] = tmp[i * 3 + 0];
+      o[1] = tmp[i * 3 + 1];
+      o[2] = tmp[i * 3 + 2];
+    }
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+// device-resident cloud, transformed by a float matrix (pcl::transformPointCloud), to the host in ORIGINAL point order
+void download_transformed(ngicp* h, DeviceCloud& dc, const float T_colmajor[16], float* out, size_t out_stride) {
+  const size_t n = dc.n;
+  h->tfinal.ensure(16 * sizeof(float));
+  h->out_xyz.ensure(n * 3 * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(h->tfinal.p, T_colmajor, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_transform_sorted_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dc.pts(), (int)n, h->tfinal.as<float>(), h->out_xyz.as<float>());
+  download_xyz(h, n, out, out_stride);
+}
+
 void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride) {
   const double t_begin = now_ms();
   h->hook_valid = 0;
@@ -797,29 +849,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   h->trace_host.clear();  // fetched on demand (ngicp_get_lm_trace): a diagnostic should not cost every align a synchronous copy
   h->trace_rows_dev = (size_t)st.hot.n_trace;
 
-  if (aligned) {
-    const size_t n = h->src.dev->n;
-    h->tfinal.ensure(16 * sizeof(float));
-    h->out_xyz.ensure(n * 3 * sizeof(float));
-    HIP_TRY(hipMemcpyAsync(h->tfinal.p, h->final_T, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_transform_out, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->src.dev->pts(), (int)n, h->tfinal.as<float>(),
-                       h->out_xyz.as<float>());
-    if (out_stride == 12) {
-      HIP_TRY(hipMemcpyAsync(aligned, h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-    } else {
-      std::vector<float> tmp(n * 3);
-      HIP_TRY(hipMemcpyAsync(tmp.data(), h->out_xyz.p, n * 12, hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      for (size_t i = 0; i < n; ++i) {
-        float* o = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(aligned) + i * out_stride);
-        o[0] = tmp[i * 3 + 0];
-        o[1] = tmp[i * 3 + 1];
-        o[2] = tmp[i * 3 + 2];
-      }
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  if (aligned) download_transformed(h, *h->src.dev, h->final_T, aligned, out_stride);  // K5: pcl::transformPointCloud(*input_, output, final_transformation_)
   ngicp_stats& s = h->stats;
   s.loop_ms = loop_ms;
   if (st.hot.have_lin) h->hook_valid = 2;  // ngicp_get_correspondences: the correspondences of the last adopted linearisation
@@ -1346,6 +1376,203 @@ int ngicp_sharded_finish(ngicp_t* h, float T_out[16], int* converged, int* nr_it
     if (nr_iterations) *nr_iterations = h->nr_iterations;
     if (final_hessian) std::memcpy(final_hessian, h->final_hessian, sizeof(h->final_hessian));
     h->sharded_active = false;
+  });
+}
+
+// ---- device-resident keyframe store + submap assembly ----
+int ngicp_keyframe_add(ngicp_t* h, ngicp_t* from, int* id_out) {
+  if (!from) return NGICP_ERR_ARG;
+  return guarded(h, [&] {
+    if (h->device != from->device) throw ArgError{NGICP_ERR_ARG, "keyframe_add across devices is not supported"};
+    ensure_slot_ready(from, from->src, "source");
+    // `keyframe_normals.push_back(gicp_s2s.getSourceCovariances())` (odom.cc:1174): the covariances the producer holds for its
+    // source; computed now if absent, with the producer's k / regularisation (calculateSourceCovariances, odom.cc:1173)
+    if (from->src_covs.n != from->src.dev->n) compute_covs(from, from->src, from->src_covs, "source");
+    (void)covs_for(from, from->src_covs, from->src.dev);  // in the cloud's own sorted order
+    HIP_TRY(hipStreamSynchronize(from->stream));          // the store is read on other streams later (keyframes are rare)
+    h->keyframes.push_back({from->src.dev, from->src_covs.data});
+    if (id_out) *id_out = (int)h->keyframes.size() - 1;
+  });
+}
+
+int ngicp_keyframe_add_transformed(ngicp_t* h, ngicp_t* from, const float T_colmajor[16], int* id_out) {
+  if (!from) return NGICP_ERR_ARG;
+  return guarded(h, [&] {
+    if (!T_colmajor) throw ArgError{NGICP_ERR_ARG, "null transform"};
+    if (h->device != from->device) throw ArgError{NGICP_ERR_ARG, "keyframe_add across devices is not supported"};
+    ensure_slot_ready(from, from->src, "source");
+    // transformCurrentScan (odom.cc:971-974) + setInputSource(keyframe_cloud) + calculateSourceCovariances (odom.cc:1172-1173),
+    // all on the device: the scan is already there as the producer's source
+    DeviceCloud& S = *from->src.dev;
+    const size_t n = S.n;
+    from->tfinal.ensure(16 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(from->tfinal.p, T_colmajor, 16 * sizeof(float), hipMemcpyHostToDevice, from->stream));
+    from->unsorted.ensure(n * sizeof(float4));
+    const int bbox_blocks = pick_blocks(n, 1024, 512);
+    from->bbox.ensure((size_t)bbox_blocks * 8 * sizeof(float));
+    hipLaunchKernelGGL(k_transform_to_unsorted, dim3(bbox_blocks), dim3(256), 0, from->stream, S.pts(), (int)n, from->tfinal.as<float>(), from->unsorted.as<float4>(),
+                       from->bbox.as<float>());
+    std::vector<float> bb((size_t)bbox_blocks * 8);
+    HIP_TRY(hipMemcpyAsync(bb.data(), from->bbox.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, from->stream));
+    HIP_TRY(hipStreamSynchronize(from->stream));
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int b = 0; b < bbox_blocks; ++b)
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = std::min(mn[d], bb[(size_t)b * 8 + d]);
+        mx[d] = std::max(mx[d], bb[(size_t)b * 8 + 3 + d]);
+      }
+    for (int d = 0; d < 3; ++d)
+      if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || mn[d] > mx[d]) throw ArgError{NGICP_ERR_ARG, "transform produced non-finite coordinates"};
+    Slot tmp;
+    tmp.present = true;
+    tmp.n = n;
+    tmp.dev = index_unsorted(from, n, mn, mx);
+    CovSet cs;
+    compute_covs(from, tmp, cs, "keyframe");
+    HIP_TRY(hipStreamSynchronize(from->stream));
+    h->keyframes.push_back({tmp.dev, cs.data});
+    if (id_out) *id_out = (int)h->keyframes.size() - 1;
+  });
+}
+
+int ngicp_keyframe_count(const ngicp_t* h, size_t* n) {
+  if (!h || !n) return NGICP_ERR_ARG;
+  *n = h->keyframes.size();
+  return NGICP_OK;
+}
+
+int ngicp_keyframe_size(const ngicp_t* h, int id, size_t* n_points) {
+  if (!h || !n_points || id < 0 || (size_t)id >= h->keyframes.size()) return NGICP_ERR_ARG;
+  *n_points = h->keyframes[(size_t)id].cloud->n;
+  return NGICP_OK;
+}
+
+int ngicp_keyframe_clear(ngicp_t* h) {
+  return guarded(h, [&] {
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->keyframes.clear();
+    h->submap_ids.clear();
+    h->submap_cloud = nullptr;
+  });
+}
+
+int ngicp_submap_set(ngicp_t* h, const int* ids, size_t n_ids, int* changed_out) {
+  return guarded(h, [&] {
+    if (changed_out) *changed_out = 0;
+    if (!ids || n_ids == 0) throw ArgError{NGICP_ERR_ARG, "empty keyframe list"};
+    size_t total = 0;
+    for (size_t i = 0; i < n_ids; ++i) {
+      if (ids[i] < 0 || (size_t)ids[i] >= h->keyframes.size()) throw ArgError{NGICP_ERR_ARG, "unknown keyframe id"};
+      total += h->keyframes[(size_t)ids[i]].cloud->n;
+    }
+    if (total > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "submap too large for int indices"};
+    // `if (submap_kf_idx_curr == submap_kf_idx_prev) submap_hasChanged = false` (odom.cc:1308-1310, 827): same keyframes, and the
+    // submap built from them is still the target -> nothing to do
+    if (h->tgt.present && h->tgt.dev && h->tgt.dev.get() == h->submap_cloud && h->submap_ids.size() == n_ids &&
+        std::equal(h->submap_ids.begin(), h->submap_ids.end(), ids) && h->tgt_covs.n == total)
+      return;
+    const double t0 = now_ms();
+    // concatenation in keyframe order (odom.cc:1318-1325): point g = offset_k + (original index inside keyframe k)
+    h->unsorted.ensure(total * sizeof(float4));
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    size_t off = 0;
+    for (size_t i = 0; i < n_ids; ++i) {
+      const ngicp::Keyframe& kf = h->keyframes[(size_t)ids[i]];
+      const int nk = (int)kf.cloud->n;
+      hipLaunchKernelGGL(k_keyframe_gather, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->stream, kf.cloud->pts(), nk, (int)off, h->unsorted.as<float4>());
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = std::min(mn[d], kf.cloud->bb_min[d]);
+        mx[d] = std::max(mx[d], kf.cloud->bb_max[d]);
+      }
+      off += (size_t)nk;
+    }
+    auto dc = index_unsorted(h, total, mn, mx);
+    ensure_inv_perm(h, *dc);
+    auto buf = acquire_buf(h->device, total * 6 * sizeof(double));
+    off = 0;
+    for (size_t i = 0; i < n_ids; ++i) {
+      const ngicp::Keyframe& kf = h->keyframes[(size_t)ids[i]];
+      const int nk = (int)kf.cloud->n;
+      hipLaunchKernelGGL(k_keyframe_covs_scatter, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, h->stream, kf.cloud->pts(), kf.covs->as<double>(), nk, (int)off,
+                         dc->inv_perm.as<int>(), buf->as<double>());
+      off += (size_t)nk;
+    }
+    HIP_TRY(hipGetLastError());
+    // setInputTarget(submap_cloud) + setTargetCovariances(submap_normals) (odom.cc:830-833)
+    h->tgt.clear();
+    h->tgt.present = true;
+    h->tgt.n = total;
+    h->tgt.dev = dc;
+    h->tgt_covs.data = buf;
+    h->tgt_covs.n = total;
+    h->tgt_covs.order = dc;
+    h->submap_ids.assign(ids, ids + n_ids);
+    h->submap_cloud = dc.get();
+    h->hook_valid = 0;
+    h->stats.submap_ms = now_ms() - t0;
+    if (changed_out) *changed_out = 1;
+  });
+}
+
+int ngicp_get_target_points(ngicp_t* h, float* xyz_out, size_t out_stride_bytes, size_t* n_out) {
+  return guarded(h, [&] {
+    ensure_slot_ready(h, h->tgt, "target");
+    const size_t n = h->tgt.dev->n;
+    if (n_out) *n_out = n;
+    if (!xyz_out) return;
+    if (out_stride_bytes < 12 || out_stride_bytes % 4) throw ArgError{NGICP_ERR_ARG, "bad out_stride_bytes"};
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    download_transformed(h, *h->tgt.dev, I, xyz_out, out_stride_bytes);
+  });
+}
+
+// ---- rigid transform of clouds ----
+int ngicp_transform_source(ngicp_t* h, const float T_colmajor[16], float* xyz_out, size_t out_stride_bytes) {
+  return guarded(h, [&] {
+    if (!T_colmajor || !xyz_out) throw ArgError{NGICP_ERR_ARG, "null pointer"};
+    if (out_stride_bytes < 12 || out_stride_bytes % 4) throw ArgError{NGICP_ERR_ARG, "bad out_stride_bytes"};
+    ensure_slot_ready(h, h->src, "source");
+    download_transformed(h, *h->src.dev, T_colmajor, xyz_out, out_stride_bytes);
+  });
+}
+
+int ngicp_transform_cloud(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, const float T_colmajor[16], float* xyz_out, size_t out_stride_bytes) {
+  return guarded(h, [&] {
+    if (n == 0) return;
+    if (!xyz || !T_colmajor || !xyz_out) throw ArgError{NGICP_ERR_ARG, "null pointer"};
+    if (stride_bytes < 12 || stride_bytes % 4 || out_stride_bytes < 12 || out_stride_bytes % 4) throw ArgError{NGICP_ERR_ARG, "bad stride"};
+    if (n > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "cloud too large for int indices"};
+    const size_t raw_bytes = (n - 1) * stride_bytes + 12;
+    h->raw.ensure(raw_bytes);
+    h->tfinal.ensure(16 * sizeof(float));
+    h->out_xyz.ensure(n * 3 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->raw.p, xyz, raw_bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->tfinal.p, T_colmajor, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_transform_raw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->raw.as<unsigned char>(), stride_bytes, (int)n, h->tfinal.as<float>(),
+                       h->out_xyz.as<float>());
+    download_xyz(h, n, xyz_out, out_stride_bytes);
+  });
+}
+
+// ---- measurement: device stream copy ----
+int ngicp_measure_copy_bandwidth(ngicp_t* h, size_t bytes, int reps, double* gbps_out) {
+  return guarded(h, [&] {
+    if (!gbps_out || bytes < 4096 || reps <= 0) throw ArgError{NGICP_ERR_ARG, "bad arguments"};
+    const size_t n16 = bytes / 16;
+    DevBuf a, b;
+    a.ensure(n16 * 16);
+    b.ensure(n16 * 16);
+    HIP_TRY(hipMemsetAsync(a.p, 1, n16 * 16, h->stream));
+    const int blocks = 256 * 8;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, h->stream, a.as<float4>(), b.as<float4>(), n16);
+    HIP_TRY(hipEventRecord(h->ev_a, h->stream));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, h->stream, a.as<float4>(), b.as<float4>(), n16);
+    HIP_TRY(hipEventRecord(h->ev_b, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev_b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    HIP_TRY(hipGetLastError());
+    *gbps_out = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;  // read + write
   });
 }
 

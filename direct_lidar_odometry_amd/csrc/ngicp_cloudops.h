@@ -1,0 +1,116 @@
+// Cloud-level kernels around the registration path: submap assembly from device-resident keyframes and the
+// rigid transform of clouds.
+//   keyframes + submap   /root/reference/src/dlo/odom.cc:1166-1174 (keyframe cloud + covariances), :1318-1325 (concatenation of
+//                        the selected keyframes' clouds and covariance vectors, in keyframe order), :827-834 (hand-over to gicp)
+//   rigid transform      pcl::transformPointCloud with a float matrix: impl/lsq_registration_impl.hpp:114, odom.cc:484,971-974
+#pragma once
+#include "ngicp_grid.h"
+
+namespace ngk {
+
+// One keyframe's cell-sorted points -> its slice of the submap's staging array, in the point order the host concatenation would
+// have produced: element (offset + original index) = {x, y, z, bitcast(offset + original index)}.  The index build that follows
+// sees exactly the cloud `*submap_cloud_ += *keyframes[k]` (odom.cc:1321) would have uploaded.
+__global__ void __launch_bounds__(256) k_keyframe_gather(const float4* __restrict__ kf_sorted, int n, int offset, float4* __restrict__ unsorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = kf_sorted[i];
+  const int g = offset + __float_as_int(p.w);
+  unsorted[g] = make_float4(p.x, p.y, p.z, __int_as_float(g));
+}
+
+// One keyframe's packed covariances (its own sorted order) -> the submap's covariance set (the submap's sorted order):
+// the device form of `submap_normals.insert(end, keyframe_normals[k].begin(), keyframe_normals[k].end())` (odom.cc:1324).
+__global__ void __launch_bounds__(256) k_keyframe_covs_scatter(const float4* __restrict__ kf_sorted, const double* __restrict__ kf_covs6, int n, int offset,
+                                                                const int* __restrict__ submap_inv_perm, double* __restrict__ submap_covs6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int pos = submap_inv_perm[offset + __float_as_int(kf_sorted[i].w)];
+  const double* s = kf_covs6 + (size_t)i * 6;
+  double* d = submap_covs6 + (size_t)pos * 6;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) d[e] = s[e];
+}
+
+// pcl::transformPointCloud with a float 4x4 (column-major here).  PCL is not part of /root/reference (nor installed here), so the
+// evaluation order is RECALLED from PCL >= 1.9's pcl/common/impl/transforms.hpp, not pinned: on x86-64 (SSE2, every DLO host)
+// detail::Transformer<float>::se3 computes  x*c0 + (y*c1 + (z*c2 + c3))  with c_j the matrix columns; the scalar fallback
+// computes ((x*m00 + y*m01) + z*m02) + m03.  The two differ by <= 1 ulp of the result.  This kernel follows the SSE2 order and
+// is built with -ffp-contract=off (no FMA, like the reference's build: CMakeLists.txt:14-15).
+__device__ __forceinline__ float3 transform_point_f(const float* __restrict__ m, float x, float y, float z) {
+  float3 o;
+  o.x = x * m[0] + (y * m[4] + (z * m[8] + m[12]));
+  o.y = x * m[1] + (y * m[5] + (z * m[9] + m[13]));
+  o.z = x * m[2] + (y * m[6] + (z * m[10] + m[14]));
+  return o;
+}
+
+// cell-sorted device cloud -> transformed xyz in ORIGINAL point order (packed, 12 B per point)
+__global__ void __launch_bounds__(256) k_transform_sorted_to_original(const float4* __restrict__ sorted, int n, const float* __restrict__ T_colmajor,
+                                                                       float* __restrict__ out_xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = sorted[i];
+  const float3 o = transform_point_f(T_colmajor, p.x, p.y, p.z);
+  float* d = out_xyz + (size_t)__float_as_int(p.w) * 3;
+  d[0] = o.x; d[1] = o.y; d[2] = o.z;
+}
+
+// cell-sorted device cloud -> transformed staging array {x', y', z', bitcast(original index)} (element = original index) + per-block
+// bounding-box partials of the transformed points, ready for the index build: a keyframe made from a scan that is already on
+// the device never visits the host (odom.cc:971-974 followed by :1166-1174).
+__global__ void __launch_bounds__(256) k_transform_to_unsorted(const float4* __restrict__ sorted, int n, const float* __restrict__ T_colmajor,
+                                                                float4* __restrict__ unsorted, float* __restrict__ bbox_part) {
+  __shared__ float lds[4][6];
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = sorted[i];
+    const float3 o = transform_point_f(T_colmajor, p.x, p.y, p.z);
+    unsorted[__float_as_int(p.w)] = make_float4(o.x, o.y, o.z, p.w);
+    mn[0] = fminf(mn[0], o.x); mx[0] = fmaxf(mx[0], o.x);
+    mn[1] = fminf(mn[1], o.y); mx[1] = fmaxf(mx[1], o.y);
+    mn[2] = fminf(mn[2], o.z); mx[2] = fmaxf(mx[2], o.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lds[wave][d] = mn[d];
+      lds[wave][3 + d] = mx[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    float v = lds[0][d];
+    for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, lds[w][d]) : fmaxf(v, lds[w][d]);
+    bbox_part[blockIdx.x * 8 + d] = v;
+  }
+  if (threadIdx.x == 6) bbox_part[blockIdx.x * 8 + 6] = 0.f;
+}
+
+// raw strided host layout (already on the device) -> transformed packed xyz, same point order
+__global__ void __launch_bounds__(256) k_transform_raw(const unsigned char* __restrict__ raw, size_t stride_bytes, int n, const float* __restrict__ T_colmajor,
+                                                        float* __restrict__ out_xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* p = reinterpret_cast<const float*>(raw + (size_t)i * stride_bytes);
+  const float3 o = transform_point_f(T_colmajor, p[0], p[1], p[2]);
+  float* d = out_xyz + (size_t)i * 3;
+  d[0] = o.x; d[1] = o.y; d[2] = o.z;
+}
+
+// device stream copy (the measured copy bandwidth reported next to the nominal HBM peak)
+__global__ void __launch_bounds__(256) k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+}  // namespace ngk

@@ -1124,19 +1124,6 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   st->hot = L;
 }
 
-// K5: output cloud = float(T) * source, in ORIGINAL order (pcl::transformPointCloud, impl/lsq_registration_impl.hpp:114)
-__global__ void __launch_bounds__(256) k_transform_out(const float4* __restrict__ src_sorted, int n, const float* __restrict__ T_colmajor, float* __restrict__ out_xyz) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = src_sorted[i];
-  const int o = __float_as_int(p.w);
-  const float* m = T_colmajor;
-  // pcl::transformPoint: x*m00 + y*m01 + z*m02 + m03 (float)
-  out_xyz[(size_t)o * 3 + 0] = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
-  out_xyz[(size_t)o * 3 + 1] = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
-  out_xyz[(size_t)o * 3 + 2] = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
-}
-
 // map correspondences (sorted source slot -> sorted target position) back to ORIGINAL indices
 __global__ void __launch_bounds__(256) k_corr_to_original(const int* __restrict__ corr, const float4* __restrict__ qpts, const float4* __restrict__ src_sorted,
                                                            const float4* __restrict__ tgt_sorted, int n, int* __restrict__ out_corr, float* __restrict__ out_sqd,

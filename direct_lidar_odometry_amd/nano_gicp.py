@@ -51,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("align_ms", C.c_double), ("loop_ms", C.c_double), ("pass_ms_total", C.c_double), ("passes", C.c_int),
                 ("outer_iterations", C.c_int), ("lm_trials", C.c_int), ("mean_candidates", C.c_double), ("valid_fraction", C.c_double),
                 ("index_build_ms", C.c_double), ("covariance_ms", C.c_double), ("upload_ms", C.c_double), ("voxel_size", C.c_double),
-                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong), ("staged_fraction", C.c_double)]
+                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong), ("staged_fraction", C.c_double), ("submap_ms", C.c_double)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -69,6 +69,8 @@ EXPORTS = [
     "ngicp_set_target_covs", "ngicp_align", "ngicp_linearize", "ngicp_compute_error", "ngicp_get_correspondences",
     "ngicp_target_knn", "ngicp_get_lm_trace", "ngicp_get_stats", "ngicp_set_profiling", "ngicp_sharded_begin",
     "ngicp_sharded_pass", "ngicp_sharded_step", "ngicp_sharded_finish",
+    "ngicp_keyframe_add", "ngicp_keyframe_add_transformed", "ngicp_keyframe_count", "ngicp_keyframe_size", "ngicp_keyframe_clear",
+    "ngicp_submap_set", "ngicp_get_target_points", "ngicp_transform_source", "ngicp_transform_cloud", "ngicp_measure_copy_bandwidth",
 ]
 
 _lib = None
@@ -119,6 +121,16 @@ def load_library() -> C.CDLL:
     L.ngicp_sharded_pass.argtypes = [vp, vp, vp]
     L.ngicp_sharded_step.argtypes = [vp, vp, vp, c_i32p]
     L.ngicp_sharded_finish.argtypes = [vp, c_f32p, c_i32p, c_i32p, c_f64p]
+    L.ngicp_keyframe_add.argtypes = [vp, vp, c_i32p]
+    L.ngicp_keyframe_add_transformed.argtypes = [vp, vp, c_f32p, c_i32p]
+    L.ngicp_keyframe_count.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.ngicp_keyframe_size.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+    L.ngicp_keyframe_clear.argtypes = [vp]
+    L.ngicp_submap_set.argtypes = [vp, c_i32p, C.c_size_t, c_i32p]
+    L.ngicp_get_target_points.argtypes = [vp, c_f32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ngicp_transform_source.argtypes = [vp, c_f32p, c_f32p, C.c_size_t]
+    L.ngicp_transform_cloud.argtypes = [vp, c_f32p, C.c_size_t, C.c_size_t, c_f32p, c_f32p, C.c_size_t]
+    L.ngicp_measure_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, c_f64p]
     _lib = L
     return L
 
@@ -341,6 +353,66 @@ class NanoGICP:
         self._ck(self._L.ngicp_get_stats(self._h, C.byref(s)))
         return s.as_dict()
 
+    # ---- device-resident keyframes + submap (replaces odom.cc:1174 and :830-833) ----
+    def addKeyframe(self, producer: "NanoGICP") -> int:
+        kid = C.c_int(-1)
+        self._ck(self._L.ngicp_keyframe_add(self._h, producer._h, C.byref(kid)))
+        return kid.value
+
+    def addKeyframeTransformed(self, producer: "NanoGICP", T) -> int:
+        kid = C.c_int(-1)
+        t = _colmajor16(T, np.float32)
+        self._ck(self._L.ngicp_keyframe_add_transformed(self._h, producer._h, _p(t, c_f32p), C.byref(kid)))
+        return kid.value
+
+    def numKeyframes(self) -> int: return self._covs_size("ngicp_keyframe_count")
+
+    def keyframeSize(self, kid: int) -> int:
+        n = C.c_size_t(0)
+        self._ck(self._L.ngicp_keyframe_size(self._h, int(kid), C.byref(n)))
+        return n.value
+
+    def clearKeyframes(self): self._ck(self._L.ngicp_keyframe_clear(self._h))
+
+    def setSubmapKeyframes(self, ids) -> bool:
+        """target := concatenation of the keyframes `ids` (cloud + covariances), on the device.  True when rebuilt."""
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        changed = C.c_int(0)
+        self._ck(self._L.ngicp_submap_set(self._h, _p(a, c_i32p), a.shape[0], C.byref(changed)))
+        self._tgt = None
+        return bool(changed.value)
+
+    def targetPoints(self) -> np.ndarray:
+        """The target cloud as the engine holds it (original point order; for a device submap: the concatenation)."""
+        n = C.c_size_t(0)
+        self._ck(self._L.ngicp_get_target_points(self._h, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.float32)
+        if n.value:
+            self._ck(self._L.ngicp_get_target_points(self._h, _p(out, c_f32p), 12, C.byref(n)))
+        return out
+
+    # ---- rigid transform of clouds (SURVEY.md §8f-3; pcl::transformPointCloud with a float matrix) ----
+    def transformSource(self, T) -> np.ndarray:
+        if self._src is None:
+            raise NgicpError(-3, "no source cloud")
+        t = _colmajor16(T, np.float32)
+        out = np.empty((self._src.shape[0], 3), dtype=np.float32)
+        self._ck(self._L.ngicp_transform_source(self._h, _p(t, c_f32p), _p(out, c_f32p), 12))
+        return out
+
+    def transformCloud(self, cloud, T) -> np.ndarray:
+        c = _cloud(cloud)
+        t = _colmajor16(T, np.float32)
+        out = np.empty((c.shape[0], 3), dtype=np.float32)
+        self._ck(self._L.ngicp_transform_cloud(self._h, _p(c, c_f32p), c.shape[0], c.strides[0], _p(t, c_f32p), _p(out, c_f32p), 12))
+        return out
+
+    def measureCopyBandwidth(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
+        """Device float4 stream copy, (read + write) GB/s."""
+        v = C.c_double(0)
+        self._ck(self._L.ngicp_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(v)))
+        return v.value
+
     # ---- point-sharded stepping (SURVEY.md §8e.2); buffers are raw device pointers ----
     def sharded_begin(self, guess=None):
         g = _colmajor16(np.eye(4) if guess is None else guess, np.float32)
@@ -361,3 +433,19 @@ class NanoGICP:
         self.converged_ = bool(conv.value); self.nr_iterations_ = nit.value
         self.final_hessian_ = H.reshape(6, 6).T.copy()
         return self.final_transformation_
+
+
+def keyframe_covariances(target, keyframe_sizes, k: int = 20, device: int = 0) -> np.ndarray:
+    """Per-keyframe covariances of a submap that is a concatenation of keyframes, concatenated in the same order — DLO's
+    `keyframe_normals` / `submap_normals` (src/dlo/odom.cc:1172-1174,1318-1325): each keyframe's covariances come from ITS OWN
+    points only.  Used by tests and bench.py to prepare the scan-to-submap workloads."""
+    e = NanoGICP(device=device)
+    e.setCorrespondenceRandomness(k)
+    out, lo = [], 0
+    for n in keyframe_sizes:
+        e.setInputSource(np.ascontiguousarray(target[lo:lo + n]))
+        e.calculateSourceCovariances()
+        out.append(e.getSourceCovariances())
+        lo += n
+    e.close()
+    return np.concatenate(out)

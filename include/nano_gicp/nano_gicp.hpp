@@ -34,6 +34,7 @@
 #include <Eigen/StdVector>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
+#include <pcl/search/kdtree.h>
 namespace nano_gicp {
 namespace types {
 template <class P> using Cloud = pcl::PointCloud<P>;
@@ -48,7 +49,16 @@ using CovVector = std::vector<Eigen::Matrix4d, Eigen::aligned_allocator<Eigen::M
 namespace pcl {
 using PointXYZI = ngicp_compat::PointXYZI;
 template <class P> using PointCloud = ngicp_compat::PointCloud<P>;
+template <class S, class T, class Scalar = float> using Registration = ngicp_compat::Registration<S, T, Scalar>;
+namespace search {
+template <class P> using KdTree = ngicp_compat::SearchKdTree<P>;
+}
 }  // namespace pcl
+namespace Eigen {  // the two spellings DLO's members use (include/dlo/odom.h:104,133; src/dlo/odom.cc:809)
+using Matrix4f = ngicp_compat::Matrix4f;
+using Matrix4d = ngicp_compat::Matrix4d;
+template <class T> using aligned_allocator = std::allocator<T>;
+}  // namespace Eigen
 namespace nano_gicp {
 namespace types {
 template <class P> using Cloud = ngicp_compat::PointCloud<P>;
@@ -77,8 +87,12 @@ class NanoGICP {
   using PointCloudTargetPtr = typename PointCloudTarget::Ptr;
   using PointCloudTargetConstPtr = typename PointCloudTarget::ConstPtr;
   using CovVector = types::CovVector;
-  struct KdTreeReciprocal {};
-  using KdTreeReciprocalPtr = std::shared_ptr<KdTreeReciprocal>;
+#ifdef NGICP_HAVE_PCL
+  using KdTreeReciprocal = pcl::search::KdTree<PointSource>;  // as pcl::Registration<PointSource, PointTarget>
+#else
+  using KdTreeReciprocal = typename pcl::Registration<PointSource, PointTarget, Scalar>::KdTreeReciprocal;
+#endif
+  using KdTreeReciprocalPtr = typename KdTreeReciprocal::Ptr;
 
   // ---- proxies for the public data members DLO assigns to ----
   struct IndexRef {  // stands for std::shared_ptr<nanoflann::KdTreeFLANN<PointSource>> source_kdtree_
@@ -148,8 +162,11 @@ class NanoGICP {
   void setEuclideanFitnessEpsilon(double) {}               // accepted, never read by nano_gicp
   void setRANSACIterations(int) {}                         // "
   void setRANSACOutlierRejectionThreshold(double) {}       // "
-  void setSearchMethodSource(const KdTreeReciprocalPtr&, bool = false) {}  // PCL's own FLANN tree is never used
-  void setSearchMethodTarget(const KdTreeReciprocalPtr&, bool = false) {}
+  // PCL's own FLANN trees are never used by nano_gicp (DLO hands over null pointers with force_no_recompute = true so that
+  // initCompute() does not build them, odom.cc:116-120): any pointer type is accepted - pcl::search::KdTree<P>::Ptr with
+  // real PCL, the stand-in of pcl_compat.hpp without - and dropped.
+  template <class TreePtr> void setSearchMethodSource(const TreePtr&, bool /*force_no_recompute*/ = false) {}
+  template <class TreePtr> void setSearchMethodTarget(const TreePtr&, bool /*force_no_recompute*/ = false) {}
   void setLSQType(LSQ_OPTIMIZER_TYPE t) { lsq_optimizer_type_ = t; push(); }
 
   // ---- clouds (impl/nano_gicp_impl.hpp:101-139) ----
@@ -164,13 +181,18 @@ class NanoGICP {
     check(ngicp_register_source(h_, xyz(cloud), cloud->size(), sizeof(PointSource), id(cloud)), "registerInputSource");
   }
   virtual void setInputTarget(const PointCloudTargetConstPtr& cloud) {
-    if (target_ == cloud) return;
+    if (target_ == cloud && !device_target_) return;
     target_ = cloud;
+    device_target_ = false;
     check(ngicp_set_target(h_, xyz(cloud), cloud->size(), sizeof(PointTarget), id(cloud)), "setInputTarget");
   }
   virtual void clearSource() { input_.reset(); check(ngicp_clear_source(h_), "clearSource"); }
-  virtual void clearTarget() { target_.reset(); check(ngicp_clear_target(h_), "clearTarget"); }
+  virtual void clearTarget() { target_.reset(); device_target_ = false; check(ngicp_clear_target(h_), "clearTarget"); }
   virtual void swapSourceAndTarget() {  // :91-98
+    if (device_target_) {  // a device-assembled submap has no host cloud to become the input: materialise it first
+      std::fprintf(stderr, "[NanoGICP] swapSourceAndTarget(): the target is a device-resident submap; not swapped\n");
+      return;
+    }
     input_.swap(target_);
     check(ngicp_swap_source_target(h_), "swapSourceAndTarget");
   }
@@ -191,7 +213,7 @@ class NanoGICP {
   void align(PointCloudSource& output, const Matrix4& guess) {
     converged_ = false;
     set_identity(final_transformation_);
-    if (!h_ || !input_ || !target_) {  // PCL's initCompute() fails silently
+    if (!h_ || !input_ || !(target_ || device_target_)) {  // PCL's initCompute() fails silently
       std::fprintf(stderr, "[NanoGICP] align(): no input source/target\n");
       return;
     }
@@ -216,7 +238,7 @@ class NanoGICP {
   void alignPoseOnly(const Matrix4& guess) {
     converged_ = false;
     set_identity(final_transformation_);
-    if (!h_ || !input_ || !target_) return;
+    if (!h_ || !input_ || !(target_ || device_target_)) return;
     int conv = 0, nit = 0;
     int rc = ngicp_align(h_, guess.data(), final_transformation_.data(), &conv, &nit, final_hessian_.data(), nullptr, 0);
     converged_ = conv != 0;
@@ -228,6 +250,45 @@ class NanoGICP {
   const types::Matrix6d& getFinalHessian() const { return final_hessian_; }
   int getNrIterations() const { return nr_iterations_; }
   ngicp_t* handle() { return h_; }
+
+  // ---- extensions with no reference counterpart (include/ngicp.h "keyframe store", "rigid transform"): the keyframes and the
+  //      submap stay on the GPU.  In DLO they replace odom.cc:1174 (`keyframe_normals.push_back(gicp_s2s.getSourceCovariances())`)
+  //      and odom.cc:830-833 (`setInputTarget(submap_cloud); setTargetCovariances(submap_normals)`); see INTEGRATION.md ----
+  // adopt `producer`'s current source cloud + covariances as the next keyframe; returns its index (== DLO's keyframes.size() - 1)
+  int addKeyframe(NanoGICP& producer) {
+    int id = -1;
+    check(ngicp_keyframe_add(h_, producer.h_, &id), "addKeyframe");
+    return id;
+  }
+  // the same with the keyframe cloud = producer's current source transformed by T on the device (odom.cc:971-974 + 1166-1174)
+  int addKeyframeTransformed(NanoGICP& producer, const Matrix4& T) {
+    int id = -1;
+    check(ngicp_keyframe_add_transformed(h_, producer.h_, T.data(), &id), "addKeyframeTransformed");
+    return id;
+  }
+  size_t numKeyframes() const { size_t n = 0; ngicp_keyframe_count(h_, &n); return n; }
+  // target := concatenation of the given keyframes (cloud + covariances), assembled and indexed on the device; a call with
+  // the id list of the current submap is a no-op.  Returns true when the target was rebuilt.
+  bool setSubmapKeyframes(const std::vector<int>& ids) {
+    int changed = 0;
+    if (check(ngicp_submap_set(h_, ids.data(), ids.size(), &changed), "setSubmapKeyframes")) {
+      target_.reset();
+      device_target_ = true;
+    }
+    return changed != 0;
+  }
+  // pcl::transformPointCloud(*getInputSource(), out, T) computed from the device-resident source (odom.cc:971-974)
+  void transformSource(PointCloudSource& out, const Matrix4& T) {
+    if (!h_ || !input_) return;
+    out = *input_;
+    std::vector<float> xyz_out(input_->size() * 3);
+    if (!check(ngicp_transform_source(h_, T.data(), xyz_out.data(), 12), "transformSource")) return;
+    for (size_t i = 0; i < out.size(); ++i) {
+      out.points[i].data[0] = xyz_out[i * 3 + 0];
+      out.points[i].data[1] = xyz_out[i * 3 + 1];
+      out.points[i].data[2] = xyz_out[i * 3 + 2];
+    }
+  }
 
  public:  // the reference's public data members (nano_gicp.hpp:120-125)
   IndexRef source_kdtree_, target_kdtree_;
@@ -259,6 +320,7 @@ class NanoGICP {
   ngicp_t* h_ = nullptr;
   PointCloudSourceConstPtr input_;
   PointCloudTargetConstPtr target_;
+  bool device_target_ = false;  // the target is a device-assembled submap (setSubmapKeyframes): no host cloud behind it
   // defaults: impl/nano_gicp_impl.hpp:50-64, impl/lsq_registration_impl.hpp:50-63
   int num_threads_ = 0;
   int k_correspondences_ = 20;

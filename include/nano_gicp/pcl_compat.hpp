@@ -74,4 +74,25 @@ using Matrix4f = Matrix<float, 4>;
 using Matrix4d = Matrix<double, 4>;
 using Matrix6d = Matrix<double, 6>;
 
+// pcl::search::KdTree<PointT> — only ever passed around as a (null) pointer (src/dlo/odom.cc:116-120)
+template <class PointT>
+struct SearchKdTree {
+  using Ptr = std::shared_ptr<SearchKdTree<PointT>>;
+  using ConstPtr = std::shared_ptr<const SearchKdTree<PointT>>;
+};
+
+// pcl::Registration<PointSource, PointTarget, Scalar> — the names DLO's call sites spell out through the base class
+// (src/dlo/odom.cc:116: `pcl::Registration<PointType, PointType>::KdTreeReciprocalPtr temp;`) and the typedefs the
+// reference class pulls from it (include/nano_gicp/nano_gicp.hpp:60-70).
+template <class PointSource, class PointTarget, class Scalar = float>
+struct Registration {
+  using Matrix4 = Matrix<Scalar, 4>;
+  using PointCloudSource = PointCloud<PointSource>;
+  using PointCloudTarget = PointCloud<PointTarget>;
+  using KdTree = SearchKdTree<PointTarget>;
+  using KdTreePtr = typename KdTree::Ptr;
+  using KdTreeReciprocal = SearchKdTree<PointSource>;
+  using KdTreeReciprocalPtr = typename KdTreeReciprocal::Ptr;
+};
+
 }  // namespace ngicp_compat

@@ -160,6 +160,7 @@ typedef struct ngicp_stats {
   int passes_timed;         /* launches covered by pass_ms_total */
   long long n_src, n_tgt;   /* cloud sizes of the last align */
   double staged_fraction;   /* fraction of queries served through the LDS row index of their batch region */
+  double submap_ms;         /* host wall time of the last ngicp_submap_set() that rebuilt the target (enqueue + index build) */
 } ngicp_stats;
 int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
 /* HIP-event timing of the k_gicp_pass launches inside align (two event records per timed launch; off by default).
@@ -176,6 +177,45 @@ int ngicp_sharded_begin(ngicp_t* h, const float guess_colmajor[16]);
 int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* hip_stream_or_null);
 int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* hip_stream_or_null, int* done);
 int ngicp_sharded_finish(ngicp_t* h, float T_out_colmajor[16], int* converged, int* nr_iterations, double final_hessian_colmajor[36]);
+
+/* --- device-resident keyframe store + submap assembly ------------ */
+/* DLO keeps every keyframe twice on the host: its cloud (`keyframes`, src/dlo/odom.cc:1166) and its covariances
+ * (`keyframe_normals`, odom.cc:1172-1174, computed by gicp_s2s used as a covariance service), and on every change of the
+ * selected keyframe set concatenates both (odom.cc:1318-1325) and hands them to gicp (odom.cc:830-833): a re-upload, a
+ * re-index and a 128 B/point covariance image per change.  Here the keyframes stay on the device:
+ *   ngicp_keyframe_add(h, from, &id)   replaces odom.cc:1174: h's store adopts `from`'s current SOURCE cloud (already uploaded
+ *                                      and indexed by setInputSource, odom.cc:1172) and its source covariances (computed with
+ *                                      `from`'s k / regularisation if not yet present, odom.cc:1173).  No copy.  `from` may be h.
+ *   ngicp_keyframe_add_transformed     replaces odom.cc:971-974 + 1166-1174 when the submap voxel filter is off: the keyframe is
+ *                                      `from`'s current source cloud (the scan, already on the device) transformed by the float
+ *                                      matrix T (pcl::transformPointCloud), indexed and given covariances with `from`'s k, all
+ *                                      on the device.  `from`'s own source slot is left untouched.
+ *   ngicp_submap_set(h, ids, n, &chg)  replaces odom.cc:1318-1325 + 830-833: target := the keyframes ids[0..n) concatenated in
+ *                                      that order (point g = offset_k + original index inside keyframe k, exactly the host
+ *                                      concatenation), target covariances := their covariances likewise; one index build, no
+ *                                      host traffic.  A call with the id list the current target was built from is a no-op
+ *                                      (*chg = 0), like the submap_hasChanged test (odom.cc:827,1308).
+ * Keyframe ids are dense, in insertion order (the index DLO uses for `keyframes[k]`). */
+int ngicp_keyframe_add(ngicp_t* h, ngicp_t* from, int* id_out);
+int ngicp_keyframe_add_transformed(ngicp_t* h, ngicp_t* from, const float T_colmajor[16], int* id_out);
+int ngicp_keyframe_count(const ngicp_t* h, size_t* n);
+int ngicp_keyframe_size(const ngicp_t* h, int id, size_t* n_points);
+int ngicp_keyframe_clear(ngicp_t* h);
+int ngicp_submap_set(ngicp_t* h, const int* ids, size_t n_ids, int* changed_out_or_null);
+/* the target cloud as the engine holds it, in ORIGINAL point order (for a device-assembled submap: the concatenation).
+ * xyz_out may be NULL to query the size only. */
+int ngicp_get_target_points(ngicp_t* h, float* xyz_out_or_null, size_t out_stride_bytes, size_t* n_out_or_null);
+
+/* --- rigid transform of clouds ------------------------------------ */
+/* pcl::transformPointCloud(in, out, Eigen::Matrix4f) — impl/lsq_registration_impl.hpp:114, src/dlo/odom.cc:484,971-974.
+ * ngicp_transform_source: the handle's current source cloud (already on the device) -> host, original point order;
+ * ngicp_transform_cloud: any host cloud -> host (upload, transform, download).  Float arithmetic in PCL's order, no FMA. */
+int ngicp_transform_source(ngicp_t* h, const float T_colmajor[16], float* xyz_out, size_t out_stride_bytes);
+int ngicp_transform_cloud(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, const float T_colmajor[16], float* xyz_out, size_t out_stride_bytes);
+
+/* --- measurement: device stream copy -------------------------------- */
+/* float4 grid-stride copy of `bytes` bytes, `reps` times on the handle's stream, HIP-event timed: (read + write) GB/s. */
+int ngicp_measure_copy_bandwidth(ngicp_t* h, size_t bytes, int reps, double* gbps_out);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,26 @@ struct CloudView {
 };
 
 // ----------------------------------------------------------------------------
+// pcl::transformPointCloud with a float matrix (impl/lsq_registration_impl.hpp:114; src/dlo/odom.cc:484,971-974).  PCL is a
+// third-party dependency that is NOT under /root/reference (PCL >= 1.10, unpinned: README.md:27) and not installed here: this
+// restates pcl/common/impl/transforms.hpp (detail::Transformer<float>::se3) FROM MEMORY -> parity unpinned.
+//   order 1 (SSE2 path, what an x86-64 build of PCL >= 1.9 executes): x*c0 + (y*c1 + (z*c2 + c3)), c_j = matrix columns
+//   order 0 (scalar fallback):                                        ((m_r0*x + m_r1*y) + m_r2*z) + m_r3
+// m is column-major.  Float arithmetic, un-fused (-ffp-contract=off).
+// ----------------------------------------------------------------------------
+inline void transform_point_pcl(const float* m, float x, float y, float z, int sse_order, float* out3) {
+  for (int r = 0; r < 3; ++r) {
+    if (sse_order) {
+      const float a = z * m[8 + r] + m[12 + r];
+      const float b = y * m[4 + r] + a;
+      out3[r] = x * m[0 + r] + b;
+    } else {
+      out3[r] = ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
 // kd-tree: restatement of the single-index static tree the reference uses
 // (nanoflann.hpp:100-102,114 => L2 metric on 3 floats, int index, leaf 100).
 // Flat node array instead of a pooled pointer tree; same split rule, same
@@ -851,7 +871,7 @@ struct Gicp {
       const float* m = final_T;
       for (size_t i = 0; i < sv.n; ++i) {
         float x = sv.at(i, 0), y = sv.at(i, 1), z = sv.at(i, 2);
-        for (int r = 0; r < 3; ++r) aligned_xyz[i * aligned_stride_floats + r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r];
+        transform_point_pcl(m, x, y, z, 1, aligned_xyz + i * aligned_stride_floats);
       }
     }
     return 0;
@@ -1068,5 +1088,11 @@ int orc_gicp_get_trace(const orc_gicp* g, double* out) {
   return 0;
 }
 double orc_gicp_lambda(const orc_gicp* g) { return g->lm_lambda; }
+
+// pcl::transformPointCloud restated (see transform_point_pcl): strided xyz in, packed xyz out
+int orc_transform_cloud(const float* xyz, size_t n, size_t stride_floats, const float T_colmajor[16], int sse_order, float* out_xyz) {
+  for (size_t i = 0; i < n; ++i) transform_point_pcl(T_colmajor, xyz[i * stride_floats], xyz[i * stride_floats + 1], xyz[i * stride_floats + 2], sse_order, out_xyz + i * 3);
+  return 0;
+}
 
 }  // extern "C"

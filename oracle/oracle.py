@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.orc_gicp_lambda.argtypes = [C.c_void_p]
         L.orc_gicp_lambda.restype = C.c_double
         L.orc_gicp_set_debug.argtypes = [C.c_void_p, C.c_int]
+        L.orc_transform_cloud.argtypes = [c_f32p, C.c_size_t, C.c_size_t, c_f32p, C.c_int, c_f32p]
         _lib = L
     return _lib
 
@@ -143,6 +144,15 @@ def covariances(pts, k: int = 20, reg: int = 3, threads: int = 8) -> np.ndarray:
     if rc:
         raise RuntimeError(f"orc_covariances rc={rc}")
     return out.reshape(-1, 4, 4).transpose(0, 2, 1)  # column-major -> [i][r][c]
+
+
+def transform_cloud(pts, T, sse_order: bool = True) -> np.ndarray:
+    """pcl::transformPointCloud(in, out, Eigen::Matrix4f) restated (ngicp_oracle.cpp transform_point_pcl; parity unpinned)."""
+    pts = _xyz(pts)
+    t = np.ascontiguousarray(np.asarray(T, dtype=np.float32).T.reshape(16))
+    out = np.empty((pts.shape[0], 3), dtype=np.float32)
+    lib().orc_transform_cloud(_fp(pts, c_f32p), pts.shape[0], pts.shape[1], _fp(t, c_f32p), 1 if sse_order else 0, _fp(out, c_f32p))
+    return out
 
 
 def so3_exp(w) -> np.ndarray:

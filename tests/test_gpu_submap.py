@@ -1,0 +1,150 @@
+"""GPU tests (-m gpu) of the rows SURVEY.md §8f lists next to the registration path:
+  f1  device-resident keyframe store + submap assembly   (src/dlo/odom.cc:1166-1174, 1240-1331, 827-834)
+  f3  rigid transform of clouds                          (impl/lsq_registration_impl.hpp:114, odom.cc:484, 971-974)
+Checker: the CPU oracle fed the host-concatenated cloud + covariances (f1) / the oracle's restatement of
+pcl::transformPointCloud (f3; PCL's source is not under /root/reference: parity unpinned, see ngicp_oracle.cpp)."""
+import numpy as np
+import pytest
+
+from direct_lidar_odometry_amd import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ng(hip_lib):
+    from direct_lidar_odometry_amd import nano_gicp
+    return nano_gicp
+
+
+def _dlo_pair(ng):
+    s2s, s2m = ng.NanoGICP(), ng.NanoGICP()
+    for e, k, d in ((s2s, 10, 1.0), (s2m, 20, 0.5)):  # odom.cc:100-114 with cfg/params.yaml:54-71
+        e.setCorrespondenceRandomness(k); e.setMaxCorrespondenceDistance(d); e.setMaximumIterations(32); e.setTransformationEpsilon(0.01)
+    return s2s, s2m
+
+
+def test_submap_from_device_keyframes_matches_host_route_and_oracle(ng, oracle_mod):
+    """odom.cc:1166-1174 (five keyframes, covariances by gicp_s2s with ITS k), :1318-1325 (concatenation in keyframe order),
+    :827-834 (hand-over + align): the device route must equal the reference's host route bit for bit and the oracle within
+    the north-star tolerance."""
+    w = clouds.scan_to_submap(20_000, 5)
+    kfs = np.split(w.target, np.cumsum(w.keyframe_sizes)[:-1])
+    s2s, s2m = _dlo_pair(ng)
+    normals = []
+    for kf in kfs:
+        s2s.setInputSource(kf); s2s.calculateSourceCovariances()             # odom.cc:1172-1173
+        normals.append(s2s.getSourceCovariances())                            # odom.cc:1174 (host route)
+        assert s2m.addKeyframe(s2s) == len(normals) - 1                       # device route: nothing leaves the GPU
+    assert s2m.numKeyframes() == 5 and [s2m.keyframeSize(i) for i in range(5)] == w.keyframe_sizes
+    ids = [0, 1, 2, 3, 4]
+    # device route
+    s2m.setInputSource(w.source)
+    assert s2m.setSubmapKeyframes(ids) is True
+    assert s2m.setSubmapKeyframes(ids) is False                                # unchanged keyframe set: no-op (odom.cc:827,1308)
+    assert np.array_equal(s2m.targetPoints(), w.target)                       # the concatenation, in the host's point order
+    assert np.array_equal(s2m.getTargetCovariances(), np.concatenate(normals))
+    s2m.align(w.guess)
+    T_dev, it_dev, tr_dev = s2m.getFinalTransformation().copy(), s2m.nr_iterations_, s2m.lm_trace().copy()
+    c_dev, _ = s2m.correspondences()
+    submap_ms = s2m.stats()["submap_ms"]
+    # host route on a fresh engine (odom.cc:830-833)
+    ref = _dlo_pair(ng)[1]
+    ref.setInputSource(w.source); ref.setInputTarget(w.target); ref.setTargetCovariances(np.concatenate(normals))
+    ref.align(w.guess)
+    assert np.array_equal(T_dev, ref.getFinalTransformation()) and it_dev == ref.nr_iterations_
+    assert np.array_equal(tr_dev[:, [0, 1, 7]], ref.lm_trace()[:, [0, 1, 7]]) and np.allclose(tr_dev, ref.lm_trace(), rtol=1e-9, atol=0)
+    assert np.array_equal(c_dev, ref.correspondences()[0])                    # ORIGINAL target indices = offset_k + index in keyframe
+    # oracle fed the host-concatenated cloud + covariances
+    o = oracle_mod.OracleGICP()
+    o.setCorrespondenceRandomness(20); o.setMaxCorrespondenceDistance(0.5); o.setMaximumIterations(32); o.setTransformationEpsilon(0.01)
+    o.setInputSource(w.source); o.setInputTarget(w.target); o.setTargetCovariances(np.concatenate(normals))
+    o.setSourceCovariances(s2m.getSourceCovariances())
+    o.align(w.guess)
+    dt, dr = clouds.pose_error(T_dev, o.getFinalTransformation())
+    assert dt <= 1e-4 and dr <= 1e-4 and it_dev == o.nr_iterations and s2m.converged_ == o.converged
+    print(f"submap of 5 x 20k assembled + indexed on the device in {submap_ms:.3f} ms (host wall)")
+
+
+def test_submap_subsets_order_and_errors(ng, oracle_mod):
+    w = clouds.scan_to_submap(6_000, 4)
+    kfs = np.split(w.target, np.cumsum(w.keyframe_sizes)[:-1])
+    s2s, s2m = _dlo_pair(ng)
+    normals = []
+    for kf in kfs:
+        s2s.setInputSource(kf); s2s.calculateSourceCovariances(); normals.append(s2s.getSourceCovariances())
+        s2m.addKeyframe(s2s)
+    s2m.setInputSource(w.source)
+    for ids in ([0], [1, 3], [3, 0, 2], [0, 1, 2, 3]):
+        assert s2m.setSubmapKeyframes(ids)
+        assert np.array_equal(s2m.targetPoints(), np.concatenate([kfs[i] for i in ids]))
+        assert np.array_equal(s2m.getTargetCovariances(), np.concatenate([normals[i] for i in ids]))
+        s2m.align(w.guess)
+        ref = _dlo_pair(ng)[1]
+        ref.setInputSource(w.source); ref.setInputTarget(np.concatenate([kfs[i] for i in ids])); ref.setTargetCovariances(np.concatenate([normals[i] for i in ids]))
+        ref.align(w.guess)
+        assert np.array_equal(s2m.getFinalTransformation(), ref.getFinalTransformation())
+    # a host target replaces the submap; the same ids then rebuild it
+    s2m.setInputTarget(kfs[0]); s2m.setTargetCovariances(normals[0])
+    assert s2m.setSubmapKeyframes([0, 1, 2, 3]) is True
+    with pytest.raises(ng.NgicpError):
+        s2m.setSubmapKeyframes([0, 7])
+    with pytest.raises(ng.NgicpError):
+        s2m.setSubmapKeyframes([])
+    # covariances computed on demand with the producer's k when the producer has none yet (odom.cc:1173)
+    s2s.setInputSource(kfs[1])
+    kid = s2m.addKeyframe(s2s)
+    s2m.setSubmapKeyframes([kid])
+    assert np.array_equal(s2m.getTargetCovariances(), normals[1])
+    s2m.clearKeyframes()
+    assert s2m.numKeyframes() == 0
+    with pytest.raises(ng.NgicpError):
+        s2m.setSubmapKeyframes([0])
+
+
+def test_keyframe_from_transformed_device_scan(ng, oracle_mod):
+    """odom.cc:971-974 (transformCurrentScan) + 1166-1174 with the submap voxel filter off: the keyframe is the current scan
+    (already on the device as gicp_s2s's source) moved by T and given covariances with gicp_s2s's k - without a host visit."""
+    w = clouds.scan_to_scan(10_000)
+    T = clouds.make_pose((1.0, -0.5, 0.2), (1.0, -2.0, 30.0)).astype(np.float32)
+    s2s, s2m = _dlo_pair(ng)
+    s2s.setInputSource(w.source)
+    kid = s2m.addKeyframeTransformed(s2s, T)
+    s2m.setSubmapKeyframes([kid])
+    moved = oracle_mod.transform_cloud(w.source, T)
+    assert np.array_equal(s2m.targetPoints(), moved)                          # bit-exact float transform (PCL's SSE2 order)
+    s2s.setInputSource(moved); s2s.calculateSourceCovariances()               # the reference's route for the same keyframe
+    assert np.array_equal(s2m.getTargetCovariances(), s2s.getSourceCovariances())
+    ties = np.zeros(len(moved), bool)
+    _, d2 = oracle_mod.OracleTree(moved).knn(moved, 11)
+    ties = d2[:, 9] == d2[:, 10]
+    assert np.abs(s2m.getTargetCovariances() - oracle_mod.covariances(moved, 10))[~ties].max() < 1e-9
+
+
+def test_transform_cloud_matches_oracle_restatement(ng, oracle_mod):
+    """pcl::transformPointCloud with a float matrix (impl/lsq_registration_impl.hpp:114; odom.cc:484,971-974)."""
+    w = clouds.scan_to_scan(10_000)
+    rng = np.random.default_rng(3)
+    g = ng.NanoGICP(); g.setMaxCorrespondenceDistance(1.0)
+    g.setInputSource(clouds.to_xyzi(w.source)); g.setInputTarget(w.target)
+    for T in (np.eye(4), clouds.make_pose((0.3, 0.1, 0.02), (0.5, -0.3, 2.0)), clouds.make_pose((-12.5, 40.0, 3.3), (170.0, -80.0, 33.0))):
+        T = T.astype(np.float32)
+        ref = oracle_mod.transform_cloud(w.source, T)
+        assert np.array_equal(g.transformSource(T), ref)                      # device-resident source, original point order
+        assert np.array_equal(g.transformCloud(clouds.to_xyzi(w.source), T), ref)  # 32-byte PointXYZI stride in, packed out
+        other = oracle_mod.transform_cloud(w.source, T, sse_order=False)      # PCL's scalar fallback order: within 1 ulp
+        assert np.abs(ref - other).max() <= np.spacing(np.abs(ref).max())
+        assert np.abs(ref.astype(np.float64) - (w.source.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3])).max() < 1e-4
+    big = (rng.normal(size=(300_001, 3)) * 30).astype(np.float32)             # not a multiple of the block size
+    T = clouds.make_pose((1, 2, 3), (10, 20, 30)).astype(np.float32)
+    assert np.array_equal(g.transformCloud(big, T), oracle_mod.transform_cloud(big, T))
+    assert g.transformCloud(np.zeros((0, 3), np.float32), T).shape == (0, 3)
+    # K5: the aligned output cloud of align() is the same kernel with the final float matrix
+    out = g.align(want_aligned=True)
+    assert np.array_equal(out, oracle_mod.transform_cloud(w.source, g.getFinalTransformation()))
+
+
+def test_copy_bandwidth_is_measured(ng):
+    g = ng.NanoGICP()
+    bw = g.measureCopyBandwidth(1 << 28, 5)
+    assert 500.0 < bw < 9000.0, bw  # GB/s, read + write; MI355X nominal 8 TB/s, ~6 TB/s achievable
