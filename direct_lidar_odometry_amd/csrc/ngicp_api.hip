@@ -246,7 +246,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
-  DevBuf dbg, grp_order, grp_cost, batch_far;
+  DevBuf dbg, dbg_q, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
@@ -666,6 +666,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.partial_pitch = nblocks;
   a.mode = 3;
   a.dbg_stamps = nullptr;
+  a.dbg_qstats = nullptr;
   {
     // rings worth staging: enough to cover the distance gate (the search never looks farther), at most kStageMaxGrow
     int need = kStageMaxGrow;
@@ -794,6 +795,12 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)c.nblocks * 4 * 16 * sizeof(unsigned long long), h->stream));
     c.pa.dbg_stamps = h->dbg.as<unsigned long long>();
   }
+  const char* qstat_path = std::getenv("NGICP_DEBUG_QSTATS");  // diagnostic only: per-query search statistics of the last pass
+  if (qstat_path) {
+    h->dbg_q.ensure((size_t)c.pa.n_src * sizeof(int4));
+    HIP_TRY(hipMemsetAsync(h->dbg_q.p, 0, (size_t)c.pa.n_src * sizeof(int4), h->stream));
+    c.pa.dbg_qstats = h->dbg_q.as<int4>();
+  }
   const long max_passes = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? (long)h->p.max_iter : (long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1;
   int chunk = h->chunk_pairs;
   HIP_TRY(hipEventRecord(h->ev_a, h->stream));
@@ -837,6 +844,14 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     HIP_TRY(hipMemcpy(hs.data(), h->dbg.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(stamp_path, "wb")) {
       std::fwrite(hs.data(), sizeof(unsigned long long), hs.size(), f);
+      std::fclose(f);
+    }
+  }
+  if (qstat_path) {
+    std::vector<int> hq((size_t)c.pa.n_src * 4);
+    HIP_TRY(hipMemcpy(hq.data(), h->dbg_q.p, hq.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(qstat_path, "wb")) {
+      std::fwrite(hq.data(), sizeof(int), hq.size(), f);
       std::fclose(f);
     }
   }
@@ -1563,7 +1578,7 @@ int ngicp_measure_copy_bandwidth(ngicp_t* h, size_t bytes, int reps, double* gbp
     a.ensure(n16 * 16);
     b.ensure(n16 * 16);
     HIP_TRY(hipMemsetAsync(a.p, 1, n16 * 16, h->stream));
-    const int blocks = 256 * 8;
+    const unsigned blocks = (unsigned)((n16 + 1023) / 1024);
     for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, h->stream, a.as<float4>(), b.as<float4>(), n16);
     HIP_TRY(hipEventRecord(h->ev_a, h->stream));
     for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, h->stream, a.as<float4>(), b.as<float4>(), n16);

@@ -54,6 +54,16 @@ __device__ __forceinline__ float unexplored_bound_sq(const Grid& g, float qx, fl
   return best * best;
 }
 
+// lower bound of the squared distance from a query (cell row cy, cz) to anything in grid row (ry, rz): the (y,z) gap to its cells
+__device__ __forceinline__ float row_gap_sq(const Grid& g, int ry, int rz, int cy, int cz, float qy, float qz) {
+  float gy = 0.f, gz = 0.f;
+  if (ry > cy) gy = (g.oy + (float)ry * g.h) - qy; else if (ry < cy) gy = qy - (g.oy + (float)(ry + 1) * g.h);
+  if (rz > cz) gz = (g.oz + (float)rz * g.h) - qz; else if (rz < cz) gz = qz - (g.oz + (float)(rz + 1) * g.h);
+  gy = fmaxf(gy - g.slack, 0.f);
+  gz = fmaxf(gz - g.slack, 0.f);
+  return gy * gy + gz * gz;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Build kernels
 // ---------------------------------------------------------------------------------------------

@@ -108,6 +108,98 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
   }
 }
 
+// Exact k-NN of the cloud's OWN point at sorted position p (the covariance kernel's query), pruned:
+//   bound   the 2*ceil(k/2)+1 points around p in the cell-sorted array (p itself included) are genuine points of the cloud, so the
+//           LARGEST of their squared distances, R2, bounds the k-th neighbour distance from above: at least k points lie within it.
+//           (A list-based bound - "closer than the current k-th best" - only exists once the list holds k entries; until then
+//           this inclusive bound stands in: candidates with d <= R2 are accepted, so the list is guaranteed to fill.)
+//   rows    only (y,z) rows of cells whose gap to the query is within the bound are visited (at most a 5 x 5 window: a looser
+//           bound takes the ring search above), the query's own row first, started at p itself;
+//   walk    a row of cells is one x-sorted run: it is walked outward from where the query's x sits, eight points per round
+//           trip, right then left, each side only while |dx|^2 + (y,z)-gap can still beat the bound.
+// Every position is visited at most once (no duplicates in the list).  Ties: first visited stays in front (strict '<'), as in
+// knn_search; the visiting order differs, so among EXACTLY equal distances another index may be kept (SURVEY.md §7 "Ties").
+template <int K>
+__device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, int s, int e, int m, float qx, float qy, float qz, float gap, int k, TopK<K>& top,
+                                             float& worst) {
+  m = min(max(m, s), e - 1);
+  for (int w = m; w < e; w += 8) {  // [m, e)
+    float4 c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = sorted[min(w + j, e - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = sqdist(qx, qy, qz, c[j]);
+      if (w + j < e && d < worst) {
+        top.insert(d, w + j);
+        worst = fminf(worst, top.kth(k));
+      }
+    }
+    const float dr = c[7].x - qx;  // the window's (or the run's) last point: everything beyond has a larger x
+    if (dr > 0.f && dr * dr + gap > worst) break;
+  }
+  for (int w = m - 8; w + 8 > s; w -= 8) {  // [s, m), nearest window first
+    float4 c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = sorted[max(w + j, s)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = sqdist(qx, qy, qz, c[j]);
+      if (w + j >= s && d < worst) {
+        top.insert(d, w + j);
+        worst = fminf(worst, top.kth(k));
+      }
+    }
+    const float dl = qx - c[0].x;
+    if (dl > 0.f && dl * dl + gap > worst) break;
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void knn_self(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, int p, const float4 q, int k,
+                                         TopK<K>& top) {
+  // the array is framed by kSortedPad >= 16 far-away sentinels: near its ends the window meets them, R2 becomes +inf and the
+  // ring search takes over (as it does for any point whose array neighbours are far away)
+  const int half = (k + 1) >> 1;
+  float R2 = 0.f;
+  for (int j0 = -half; j0 <= half; j0 += 8) {
+    float d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = sqdist(q.x, q.y, q.z, sorted[p + min(j0 + j, half)]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) R2 = fmaxf(R2, d[j]);
+  }
+  const float reach = sqrtf(R2) + g.slack;
+  if (!(R2 < 3.0e38f) || !(reach < 1.999f * g.h)) {
+    knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
+    return;
+  }
+  const int rr = (int)(reach * g.inv_h * 1.0001f) + 1;  // rows farther than rr cells away lie beyond the bound (1 or 2)
+  top.init();
+  float worst = fmaxf(__uint_as_float(__float_as_uint(R2) + 1u), 1.1754944e-38f);  // smallest float above R2: "d <= R2" as a strict test
+  int cx, cy, cz;
+  cell_coords(g, q.x, q.y, q.z, cx, cy, cz);
+  const int xa = max(cx - rr, 0), xb = min(cx + rr, g.nx - 1);
+  {
+    const int row = (cz * g.ny + cy) * g.nx;
+    knn_walk_row<K>(sorted, cell_start[row + xa], cell_start[row + xb + 1], p, q.x, q.y, q.z, 0.f, k, top, worst);
+  }
+  const float xfrac_den = 1.0f / ((float)(xb + 1 - xa) * g.h), xrel = q.x - (g.ox + (float)xa * g.h);
+  const int side = 2 * rr + 1;
+  for (int t = 0; t < side * side; ++t) {
+    const int dz = t / side - rr, dy = t % side - rr;
+    const int y = cy + dy, z = cz + dz;
+    if ((dy == 0 && dz == 0) || y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+    const float gap = row_gap_sq(g, y, z, cy, cz, q.y, q.z);
+    if (gap > worst) continue;
+    const int row = (z * g.ny + y) * g.nx;
+    const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
+    if (e <= s) continue;
+    const float frac = fminf(fmaxf(xrel * xfrac_den, 0.f), 1.f);
+    knn_walk_row<K>(sorted, s, e, s + (int)(frac * (float)(e - s)), q.x, q.y, q.z, gap, k, top, worst);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: covariance of every point of an indexed cloud (thread per point, sorted order)
 // covs6[i] = {xx,xy,xz,yy,yz,zz} of the regularised 3x3 (FP64), i = sorted position.
@@ -121,7 +213,7 @@ __global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ 
   if (i >= n) return;
   const float4 q = sorted[i];
   TopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
+  knn_self<K>(g, sorted, cell_start, i, q, k, top);
 
   // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k
   double mx = 0, my = 0, mz = 0;
@@ -133,7 +225,6 @@ __global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ 
       my += (double)p.y;
       mz += (double)p.z;
     }
-  const double inv_k = 1.0 / (double)k;
   mx = mx / (double)k;
   my = my / (double)k;
   mz = mz / (double)k;
@@ -146,7 +237,6 @@ __global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ 
       C[0] += x * x; C[1] += x * y; C[2] += x * z;
       C[3] += y * y; C[4] += y * z; C[5] += z * z;
     }
-  (void)inv_k;
 #pragma unroll
   for (int e = 0; e < 6; ++e) C[e] = C[e] / (double)k;
 

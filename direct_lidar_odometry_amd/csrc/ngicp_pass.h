@@ -95,7 +95,8 @@ struct PassArgs {
   int partial_pitch;        // >= number of groups
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
   int stage_grow;           // rings around the batch box that the LDS row list covers (0: no list, search unindexed)
-  unsigned long long* dbg_stamps;  // diagnostic build only: [wave][16] s_memtime stamps, or null
+  unsigned long long* dbg_stamps;  // diagnostic only: [wave][16] s_memtime stamps, or null
+  int4* dbg_qstats;                // diagnostic only: per query {ring-1 candidates, ring-1 walks | far walks << 16, far + shell candidates, flags}, or null
 };
 
 // --- cooperative exact 1-NN ------------------------------------------------------------------
@@ -248,22 +249,13 @@ struct WaveStage {
   float4 qtab[32];              // per query: transformed coordinates
   int units[kUnitCap];          // query | row code << 8
   int q_tail, q_head;
+  int qstat[32][3];             // diagnostic counters (PassArgs::dbg_qstats)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// lower bound of the squared distance from a query (cell row cy, cz) to anything in grid row (ry, rz): the (y,z) gap to its cells
-__device__ __forceinline__ float row_gap_sq(const Grid& g, int ry, int rz, int cy, int cz, float qy, float qz) {
-  float gy = 0.f, gz = 0.f;
-  if (ry > cy) gy = (g.oy + (float)ry * g.h) - qy; else if (ry < cy) gy = qy - (g.oy + (float)(ry + 1) * g.h);
-  if (rz > cz) gz = (g.oz + (float)rz * g.h) - qz; else if (rz < cz) gz = qz - (g.oz + (float)(rz + 1) * g.h);
-  gy = fmaxf(gy - g.slack, 0.f);
-  gz = fmaxf(gz - g.slack, 0.f);
-  return gy * gy + gz * gz;
 }
 
 // Outward scan of an x-sorted run [s, e) in GLOBAL memory from a starting guess m: walk right, then left, each until the
@@ -577,6 +569,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
           S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
         }
         if (lane == 0) S.q_tail = 0, S.q_head = 0;
+        if (a.dbg_qstats && lane < 32) S.qstat[lane][0] = S.qstat[lane][1] = S.qstat[lane][2] = 0;
         wave_lds_sync();
         // ---- rings 0..1: one unit per non-empty row of the query's 3 x 3 (y,z) window that its (y,z) gap does not rule out ----
         if (in_box) {
@@ -610,8 +603,13 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
             const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
             if (e0 <= s0) continue;
             const float frac = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+            const unsigned int c_before = ncand;
             scan_global_outward(a.tgt, s0, e0, s0 + (int)(frac * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
             atomicMin(&S.qkey[qs], pack_key(ub, up));
+            if (a.dbg_qstats) {
+              atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
+              atomicAdd(&S.qstat[qs][1], 1);
+            }
           }
         }
         wave_lds_sync();
@@ -673,8 +671,13 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
               const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
               const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
               const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+              const unsigned int c_before = ncand;
               scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
               atomicMin(&S.qkey[qs], pack_key(ub, up));
+              if (a.dbg_qstats) {
+                atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
+                atomicAdd(&S.qstat[qs][1], 1 << 16);
+              }
             }
           }
           wave_lds_sync();
@@ -693,7 +696,13 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
       }
       // whatever lies beyond the listed rings: rare, per query
+      const unsigned int c_before_shells = ncand;
       if (qok) nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, need_far ? grow : 1, best, pos, ncand);
+      if (a.dbg_qstats && listed) {  // wave-uniform
+        if (qok) atomicAdd(&S.qstat[grp][2], (int)(ncand - c_before_shells));
+        wave_lds_sync();
+        if (qok && sub == 0) a.dbg_qstats[qi] = make_int4(S.qstat[grp][0], S.qstat[grp][1], S.qstat[grp][2], (went_far ? 1 : 0) | (in_box ? 2 : 0) | (pos >= 0 ? 4 : 0));
+      }
       {
         const bool any_far = __any(went_far);
         if (lane == 0) a.batch_far[batch] = any_far ? 1 : 0;

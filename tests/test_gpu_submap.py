@@ -132,8 +132,8 @@ def test_transform_cloud_matches_oracle_restatement(ng, oracle_mod):
         ref = oracle_mod.transform_cloud(w.source, T)
         assert np.array_equal(g.transformSource(T), ref)                      # device-resident source, original point order
         assert np.array_equal(g.transformCloud(clouds.to_xyzi(w.source), T), ref)  # 32-byte PointXYZI stride in, packed out
-        other = oracle_mod.transform_cloud(w.source, T, sse_order=False)      # PCL's scalar fallback order: within 1 ulp
-        assert np.abs(ref - other).max() <= np.spacing(np.abs(ref).max())
+        other = oracle_mod.transform_cloud(w.source, T, sse_order=False)      # PCL's scalar fallback order: a rounding or two apart
+        assert np.abs(ref - other).max() <= 3 * np.spacing(np.abs(ref).max())
         assert np.abs(ref.astype(np.float64) - (w.source.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3])).max() < 1e-4
     big = (rng.normal(size=(300_001, 3)) * 30).astype(np.float32)             # not a multiple of the block size
     T = clouds.make_pose((1, 2, 3), (10, 20, 30)).astype(np.float32)
