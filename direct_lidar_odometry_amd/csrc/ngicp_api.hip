@@ -89,7 +89,9 @@ struct DeviceCloud {
   DevBuf perm;        // int[n]    sorted position -> original index
   DevBuf inv_perm;    // int[n]    original index -> sorted position (lazily built)
   bool has_inv = false;
-  DevBuf cell_start;  // int[ncells + 1]
+  DevBuf cell_start;  // int[kCellPad + ncells + 1 + kCellPad]: the exclusive prefix of points per cell, framed by kCellPad entries on each side (0 in
+                      // front, n behind) so that the pass may fetch the four bounds around a cell with ONE 16-byte load at any cell
+  int* cells() const { return cell_start.as<int>() + kCellPad; }
   DevBuf qpts;        // float4[n]  the points in Morton-tile query order, w = sorted position
   DevBuf batches;     // int2[n_batches] {first qpts index, count <= 32}: tile-aligned query batches
   DevBuf n_batches_dev;
@@ -323,12 +325,13 @@ void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_ho
   const int ntiles = (g.ncells + kScanTile - 1) / kScanTile;
   h->tile_sums.ensure((size_t)ntiles * sizeof(int));
   h->tile_sq.ensure((size_t)ntiles * sizeof(unsigned long long));
-  dc.cell_start.ensure((size_t)(g.ncells + 1) * sizeof(int));
+  dc.cell_start.ensure((size_t)(g.ncells + 1 + 2 * kCellPad) * sizeof(int));
+  HIP_TRY(hipMemsetAsync(dc.cell_start.p, 0, kCellPad * sizeof(int), h->stream));  // front pad (k_scan_apply writes the back pad)
   unsigned long long* tsq = (occ_host || occ_device_only) ? h->tile_sq.as<unsigned long long>() : nullptr;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), g.ncells, h->tile_sums.as<int>(), tsq);
   hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)tsq,
                      h->occ.as<unsigned long long>());
-  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), g.ncells, h->tile_sums.as<int>(), dc.cell_start.as<int>());
+  hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), g.ncells, h->tile_sums.as<int>(), dc.cells());
   if (occ_host) {
     HIP_TRY(hipMemcpyAsync(occ_host, h->occ.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -422,9 +425,9 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
   dc->sorted.ensure((n + 2 * kSortedPad) * sizeof(float4));
   hipLaunchKernelGGL(k_fill_sentinels, dim3(1), dim3(2 * kSortedPad), 0, h->stream, dc->sorted.as<float4>(), ni);
   dc->perm.ensure(n * sizeof(int));
-  hipLaunchKernelGGL(k_cell_scatter, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), h->keys.as<int>(), ni, dc->cell_start.as<int>(),
+  hipLaunchKernelGGL(k_cell_scatter, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), h->keys.as<int>(), ni, dc->cells(),
                      h->fill.as<int>(), h->tmp.as<float4>());
-  hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cell_start.as<int>(), dc->pts(),
+  hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cells(), dc->pts(),
                      dc->perm.as<int>());
   {
     // query order (Morton over tiles of 2^shift cells; <= 128 tiles per axis => <= 2M histogram bins)
@@ -434,7 +437,7 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
     while ((1 << bits) <= ((std::max(g.nx, std::max(g.ny, g.nz)) - 1) >> shift)) ++bits;
     const int nbins = 1 << (3 * bits);
     h->counts.ensure((size_t)(nbins + 1) * sizeof(int));
-    h->fill.ensure((size_t)(nbins + 1) * sizeof(int));  // reused as tile_start
+    h->fill.ensure((size_t)(nbins + 1 + kCellPad) * sizeof(int));  // reused as tile_start (k_scan_apply pads its output)
     HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(nbins + 1) * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_tile_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, h->counts.as<int>());
     const int ntiles = (nbins + kScanTile - 1) / kScanTile;
@@ -444,11 +447,11 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
                        (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), h->fill.as<int>());
     dc->qpts.ensure(n * sizeof(float4));
-    hipLaunchKernelGGL(k_tile_place, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, dc->cell_start.as<int>(),
+    hipLaunchKernelGGL(k_tile_place, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, dc->cells(),
                        h->fill.as<int>(), dc->qpts.as<float4>());
     // tile-aligned query batches
     h->keys.ensure((size_t)(nbins + 1) * sizeof(int));   // batches per tile
-    h->tmp.ensure((size_t)(nbins + 1) * sizeof(int));    // exclusive scan of it
+    h->tmp.ensure((size_t)(nbins + 1 + kCellPad) * sizeof(int));    // exclusive scan of it
     dc->batches.ensure((n + 1) * sizeof(int2));
     dc->n_batches_dev.ensure(sizeof(int));
     hipLaunchKernelGGL(k_batch_count, dim3((nbins + 255) / 256), dim3(256), 0, h->stream, h->counts.as<int>(), nbins, h->keys.as<int>());
@@ -512,7 +515,7 @@ void ensure_slot_ready(ngicp* h, Slot& s, const char* what) {
 // ------------------------------------------------------------------------------------------
 template <int K>
 void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out) {
-  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + 127) / 128)), dim3(128), 0, h->stream, dc.pts(), dc.cell_start.as<int>(), dc.grid, (int)dc.n, k,
+  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + 127) / 128)), dim3(128), 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k,
                      reg, out);
 }
 
@@ -646,7 +649,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
   a.n_src = (int)n;
   a.tgt = T.pts();
-  a.tgt_cell_start = T.cell_start.as<int>();
+  a.tgt_cell_start = T.cells();
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
   for (int i = 0; i < 2; ++i) {
@@ -1277,13 +1280,13 @@ int ngicp_target_knn(ngicp_t* h, const float* q, size_t nq, size_t stride, int k
     HIP_TRY(hipMemcpyAsync(h->queries.p, packed.data(), nq * sizeof(float4), hipMemcpyHostToDevice, h->stream));
     const dim3 grid((unsigned)((nq + 127) / 128)), block(128);
     if (k <= 10)
-      hipLaunchKernelGGL(k_knn_queries<10>, grid, block, 0, h->stream, T.pts(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+      hipLaunchKernelGGL(k_knn_queries<10>, grid, block, 0, h->stream, T.pts(), T.cells(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());
     else if (k <= 20)
-      hipLaunchKernelGGL(k_knn_queries<20>, grid, block, 0, h->stream, T.pts(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+      hipLaunchKernelGGL(k_knn_queries<20>, grid, block, 0, h->stream, T.pts(), T.cells(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());
     else
-      hipLaunchKernelGGL(k_knn_queries<32>, grid, block, 0, h->stream, T.pts(), T.cell_start.as<int>(), T.grid, h->queries.as<float4>(), (int)nq, k,
+      hipLaunchKernelGGL(k_knn_queries<32>, grid, block, 0, h->stream, T.pts(), T.cells(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());
     HIP_TRY(hipMemcpyAsync(idx, h->knn_idx.p, nq * k * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(d2, h->knn_d2.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));

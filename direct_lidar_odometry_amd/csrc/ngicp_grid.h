@@ -210,7 +210,10 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_tile_sums(int* __restrict__
   }
 }
 
-// out[i] = exclusive prefix of counts (out has n + 1 entries; out[n] = total)
+// The cell-start table is framed by kCellPad entries on each side (0 in front, the total behind): the four bounds around any cell
+// are then one 16-byte load (see k_gicp_pass).
+constexpr int kCellPad = 4;
+// out[i] = exclusive prefix of counts (out has n + 1 entries; out[n] = total, repeated kCellPad times behind it)
 __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int* __restrict__ counts, int n, const int* __restrict__ tile_offsets, int* __restrict__ out) {
   __shared__ int lds[8];
   const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
@@ -229,7 +232,10 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int* __restrict
     int i = base + j;
     if (i < n) out[i] = ex;
     ex += c[j];
-    if (i == n - 1) out[n] = ex;
+    if (i == n - 1) {
+#pragma unroll
+      for (int t = 0; t <= kCellPad; ++t) out[n + t] = ex;
+    }
   }
 }
 

@@ -11,45 +11,79 @@
 // order differs from a kd-tree's, so among EXACTLY equal distances a different index may win
 // (SURVEY.md §7 "Ties").
 #pragma once
+#include <type_traits>
+
 #include "ngicp_grid.h"
 #include "ngicp_math.h"
 
 namespace ngk {
 
-// Sorted (ascending) top-K list in registers; all indices compile-time after unrolling.
+// Sorted (ascending) top-K list held in NAMED scalars (a recursive struct, one level per slot): an array member, even with
+// compile-time indices after unrolling, was left in private memory by the compiler at K >= 20 (164 bytes of scratch per lane,
+// every insert a round of scratch loads and stores) and promoted to LDS at K = 10.  TopK<K> = slots 0..K-2 (`head`) + slot K-1.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <int K>
 struct TopK {
-  float d[K];
-  int id[K];
+  TopK<K - 1> head;
+  float d_;
+  int id_;
   __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int s = 0; s < K; ++s) {
-      d[s] = 3.4028234664e38f;  // FLT_MAX, KNNResultSet::init (impl/nanoflann_impl.hpp:168-174)
-      id[s] = -1;
-    }
+    head.init();
+    d_ = 3.4028234664e38f;  // FLT_MAX, KNNResultSet::init (impl/nanoflann_impl.hpp:168-174)
+    id_ = -1;
   }
+  __device__ __forceinline__ float last_d() const { return d_; }
+  __device__ __forceinline__ int last_id() const { return id_; }
   // insert (dist, index) given dist < d[kth]; elements equal to dist stay in front (strict '>')
   __device__ __forceinline__ void insert(float dist, int index) {
-#pragma unroll
-    for (int s = K - 1; s >= 1; --s) {
-      const bool shift = d[s - 1] > dist;
-      const bool here = !shift && (d[s] > dist);
-      const float nd = shift ? d[s - 1] : (here ? dist : d[s]);
-      const int ni = shift ? id[s - 1] : (here ? index : id[s]);
-      d[s] = nd;
-      id[s] = ni;
-    }
-    if (d[0] > dist) {
-      d[0] = dist;
-      id[0] = index;
+    const float pd = head.last_d();  // slot K-2 before it moves
+    const int pi = head.last_id();
+    const bool shift = pd > dist;
+    const bool here = !shift && (d_ > dist);
+    d_ = shift ? pd : (here ? dist : d_);
+    id_ = shift ? pi : (here ? index : id_);
+    head.insert(dist, index);
+  }
+  __device__ __forceinline__ float d_at(int s) const { return s == K - 1 ? d_ : head.d_at(s); }  // run-time slot: a select chain
+  __device__ __forceinline__ float kth(int k) const { return d_at(k - 1); }
+  template <int S>
+  __device__ __forceinline__ float d() const {
+    if constexpr (S == K - 1) return d_; else return head.template d<S>();
+  }
+  template <int S>
+  __device__ __forceinline__ int id() const {
+    if constexpr (S == K - 1) return id_; else return head.template id<S>();
+  }
+};
+template <>
+struct TopK<1> {
+  float d_;
+  int id_;
+  __device__ __forceinline__ void init() {
+    d_ = 3.4028234664e38f;
+    id_ = -1;
+  }
+  __device__ __forceinline__ float last_d() const { return d_; }
+  __device__ __forceinline__ int last_id() const { return id_; }
+  __device__ __forceinline__ void insert(float dist, int index) {
+    if (d_ > dist) {
+      d_ = dist;
+      id_ = index;
     }
   }
-  __device__ __forceinline__ float kth(int k) const {
-    float v = d[0];
-#pragma unroll
-    for (int s = 1; s < K; ++s) v = (s == k - 1) ? d[s] : v;
-    return v;
-  }
+  __device__ __forceinline__ float d_at(int) const { return d_; }
+  __device__ __forceinline__ float kth(int) const { return d_; }
+  template <int S>
+  __device__ __forceinline__ float d() const { return d_; }
+  template <int S>
+  __device__ __forceinline__ int id() const { return id_; }
 };
 
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const float4& p) {
@@ -80,15 +114,12 @@ __device__ __forceinline__ void scan_run(const float4* __restrict__ sorted, int 
 }
 
 // Exact kNN of (qx,qy,qz) in an indexed cloud.  Result: top.id = SORTED positions, top.d ascending.
+// Ring expansion from ring r0 on (the list / `worst` hold what rings < r0 contributed; r0 = 0: a fresh search).
 template <int K>
-__device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                           int k, TopK<K>& top) {
-  top.init();
-  float worst = 3.4028234664e38f;
-  int cx, cy, cz;
-  cell_coords(g, qx, qy, qz, cx, cy, cz);
+__device__ __forceinline__ void knn_rings(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                          int cx, int cy, int cz, int k, int r0, TopK<K>& top, float& worst) {
   const int rmax = max(max(g.nx, g.ny), g.nz);
-  for (int r = 0; r <= rmax; ++r) {
+  for (int r = r0; r <= rmax; ++r) {
     const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
     const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
@@ -108,15 +139,26 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
   }
 }
 
-// Exact k-NN of the cloud's OWN point at sorted position p (the covariance kernel's query), pruned:
-//   bound   the 2*ceil(k/2)+1 points around p in the cell-sorted array (p itself included) are genuine points of the cloud, so the
-//           LARGEST of their squared distances, R2, bounds the k-th neighbour distance from above: at least k points lie within it.
-//           (A list-based bound - "closer than the current k-th best" - only exists once the list holds k entries; until then
-//           this inclusive bound stands in: candidates with d <= R2 are accepted, so the list is guaranteed to fill.)
-//   rows    only (y,z) rows of cells whose gap to the query is within the bound are visited (at most a 5 x 5 window: a looser
-//           bound takes the ring search above), the query's own row first, started at p itself;
-//   walk    a row of cells is one x-sorted run: it is walked outward from where the query's x sits, eight points per round
-//           trip, right then left, each side only while |dx|^2 + (y,z)-gap can still beat the bound.
+template <int K>
+__device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                           int k, TopK<K>& top) {
+  top.init();
+  float worst = 3.4028234664e38f;
+  int cx, cy, cz;
+  cell_coords(g, qx, qy, qz, cx, cy, cz);
+  knn_rings<K>(g, sorted, cell_start, qx, qy, qz, cx, cy, cz, k, 0, top, worst);
+}
+
+// Exact k-NN of the cloud's OWN point at sorted position p (the covariance kernel's query): rings 0..1 are visited row by row
+// instead of cell by cell, and pruned:
+//   rows    a (y,z) row of the 3 x 3 window is one x-sorted run over the cells cx-1..cx+1.  The query's own row comes first,
+//           walked outward from p itself: the list fills with the nearest points of the run, and from then on the k-th best
+//           distance (`worst`) bounds everything else.  (A list-based bound only exists once the list holds k entries: until
+//           then `worst` is FLT_MAX and nothing is pruned.)  The other eight rows are skipped when their (y,z) gap alone
+//           reaches `worst`;
+//   walk    eight points per round trip, right then left of the starting position, each side only while |dx|^2 + gap can
+//           still beat `worst`;
+//   rings   if the k-th best is not provably exact after ring 1 (unexplored_bound_sq), the ring search continues at ring 2.
 // Every position is visited at most once (no duplicates in the list).  Ties: first visited stays in front (strict '<'), as in
 // knn_search; the visiting order differs, so among EXACTLY equal distances another index may be kept (SURVEY.md §7 "Ties").
 template <int K>
@@ -158,46 +200,28 @@ __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, 
 template <int K>
 __device__ __forceinline__ void knn_self(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, int p, const float4 q, int k,
                                          TopK<K>& top) {
-  // the array is framed by kSortedPad >= 16 far-away sentinels: near its ends the window meets them, R2 becomes +inf and the
-  // ring search takes over (as it does for any point whose array neighbours are far away)
-  const int half = (k + 1) >> 1;
-  float R2 = 0.f;
-  for (int j0 = -half; j0 <= half; j0 += 8) {
-    float d[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = sqdist(q.x, q.y, q.z, sorted[p + min(j0 + j, half)]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) R2 = fmaxf(R2, d[j]);
-  }
-  const float reach = sqrtf(R2) + g.slack;
-  if (!(R2 < 3.0e38f) || !(reach < 1.999f * g.h)) {
-    knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
-    return;
-  }
-  const int rr = (int)(reach * g.inv_h * 1.0001f) + 1;  // rows farther than rr cells away lie beyond the bound (1 or 2)
   top.init();
-  float worst = fmaxf(__uint_as_float(__float_as_uint(R2) + 1u), 1.1754944e-38f);  // smallest float above R2: "d <= R2" as a strict test
+  float worst = 3.4028234664e38f;
   int cx, cy, cz;
   cell_coords(g, q.x, q.y, q.z, cx, cy, cz);
-  const int xa = max(cx - rr, 0), xb = min(cx + rr, g.nx - 1);
+  const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
   {
     const int row = (cz * g.ny + cy) * g.nx;
     knn_walk_row<K>(sorted, cell_start[row + xa], cell_start[row + xb + 1], p, q.x, q.y, q.z, 0.f, k, top, worst);
   }
-  const float xfrac_den = 1.0f / ((float)(xb + 1 - xa) * g.h), xrel = q.x - (g.ox + (float)xa * g.h);
-  const int side = 2 * rr + 1;
-  for (int t = 0; t < side * side; ++t) {
-    const int dz = t / side - rr, dy = t % side - rr;
-    const int y = cy + dy, z = cz + dz;
-    if ((dy == 0 && dz == 0) || y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+  const float frac = fminf(fmaxf((q.x - (g.ox + (float)xa * g.h)) / ((float)(xb + 1 - xa) * g.h), 0.f), 1.f);
+  for (int t = 0; t < 9; ++t) {
+    const int y = cy + t % 3 - 1, z = cz + t / 3 - 1;
+    if (t == 4 || y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
     const float gap = row_gap_sq(g, y, z, cy, cz, q.y, q.z);
-    if (gap > worst) continue;
+    if (gap >= worst) continue;
     const int row = (z * g.ny + y) * g.nx;
     const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
     if (e <= s) continue;
-    const float frac = fminf(fmaxf(xrel * xfrac_den, 0.f), 1.f);
     knn_walk_row<K>(sorted, s, e, s + (int)(frac * (float)(e - s)), q.x, q.y, q.z, gap, k, top, worst);
   }
+  if (worst <= unexplored_bound_sq(g, q.x, q.y, q.z, cx, cy, cz, 1)) return;
+  knn_rings<K>(g, sorted, cell_start, q.x, q.y, q.z, cx, cy, cz, k, 2, top, worst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,26 +241,26 @@ __global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ 
 
   // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k
   double mx = 0, my = 0, mz = 0;
-#pragma unroll
-  for (int s = 0; s < K; ++s)
-    if (s < k) {
-      const float4 p = sorted[top.id[s]];
+  static_for<0, K>([&](auto S) {
+    if (S.value < k) {
+      const float4 p = sorted[top.template id<S.value>()];
       mx += (double)p.x;
       my += (double)p.y;
       mz += (double)p.z;
     }
+  });
   mx = mx / (double)k;
   my = my / (double)k;
   mz = mz / (double)k;
   double C[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int s = 0; s < K; ++s)
-    if (s < k) {
-      const float4 p = sorted[top.id[s]];
+  static_for<0, K>([&](auto S) {
+    if (S.value < k) {
+      const float4 p = sorted[top.template id<S.value>()];
       const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
       C[0] += x * x; C[1] += x * y; C[2] += x * z;
       C[3] += y * y; C[4] += y * z; C[5] += z * z;
     }
+  });
 #pragma unroll
   for (int e = 0; e < 6; ++e) C[e] = C[e] / (double)k;
 
@@ -292,13 +316,13 @@ __global__ void __launch_bounds__(128) k_knn_queries(const float4* __restrict__ 
   const float4 q = queries[i];
   TopK<K> top;
   knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
-#pragma unroll
-  for (int s = 0; s < K; ++s)
-    if (s < k) {
-      const int pos = top.id[s];
-      out_idx[(size_t)i * k + s] = pos >= 0 ? __float_as_int(sorted[pos].w) : -1;
-      out_d2[(size_t)i * k + s] = pos >= 0 ? top.d[s] : __builtin_inff();
+  static_for<0, K>([&](auto S) {
+    if (S.value < k) {
+      const int pos = top.template id<S.value>();
+      out_idx[(size_t)i * k + S.value] = pos >= 0 ? __float_as_int(sorted[pos].w) : -1;
+      out_d2[(size_t)i * k + S.value] = pos >= 0 ? top.template d<S.value>() : __builtin_inff();
     }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------

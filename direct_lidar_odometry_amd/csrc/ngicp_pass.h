@@ -232,13 +232,13 @@ constexpr int kStageMaxGrow = 6;
 #endif
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
 
-constexpr int kUnitCap = 512;         // queued (query, row) walks per round
+constexpr int kUnitCap = 288;         // queued (query, row) walks per round (ring 1 needs 32 queries x 9 rows)
 
 struct WaveStage {
   union {
     struct {
       int4 live[kStageRows];  // one record per NON-EMPTY row of the region, nearest ring first: {y | z << 16, points, first point, -}
-      unsigned short row_live[kStageRows];  // region row -> index into live[], 0xffff = empty row
+      int qstat[32][3];       // diagnostic counters (PassArgs::dbg_qstats)
     };
     double red[32 * 30];  // the per-batch reduction reuses the (then idle) tables as scratch
   };
@@ -247,9 +247,10 @@ struct WaveStage {
   // needed one row would idle.  Results meet in qkey by a 64-bit atomic min on (distance bits, position): the total order.
   unsigned long long qkey[32];  // per query: nearest so far
   float4 qtab[32];              // per query: transformed coordinates
-  int units[kUnitCap];          // query | row code << 8
+  // a unit: ring 1: {query | row code << 5 | (start - run start) << 9, run start, run end, (y,z) gap}; beyond: {query | listed row << 5}
+  int unit_q[kUnitCap], unit_s[kUnitCap], unit_e[kUnitCap];
+  float unit_g[kUnitCap];
   int q_tail, q_head;
-  int qstat[32][3];             // diagnostic counters (PassArgs::dbg_qstats)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -424,17 +425,18 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     const int i = qbase + lane;
     const bool mine = lane < qcount;
     NG_STAMP(1);
-    // ---- the tail's operands (one query per lane) are requested up front: their round trips (source point -> covariance;
-    //      old correspondence -> old target point) overlap the staging and the search.  The kernel is LDS-bound at two
-    //      waves per SIMD, so the ~35 registers this holds across the search are free ----
+    // ---- the operands of this lane's own query (lane l <-> query qbase + l: the tail's mapping) are requested up front: their
+    //      round trips (source point -> covariance; old correspondence -> old target point) overlap everything below, and the
+    //      search takes its query and its warm start from them by shuffles instead of fetching them again ----
+    const bool have_prev = st->hot.have_lin != 0;
     float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
     int j_old = -1;
     double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
     float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
       sp = a.qpts[i];
+      if (have_prev) j_old = corr_old[i];  // K4's correspondence and the search's warm start
       if (do_err) {
-        j_old = corr_old[i];
         const double* M = mahal_old + (size_t)i * 6;
 #pragma unroll
         for (int e = 0; e < 6; ++e) Mold[e] = M[e];
@@ -451,17 +453,20 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       mypos = (qbase + lane) % 1000;
       mybest = 0.01f;
     } else if (do_lin) {
-      // ---- K2 (impl/nano_gicp_impl.hpp:178,190-192): the query of this lane's group ----
+      // ---- K2 (impl/nano_gicp_impl.hpp:178,190-192): the query of this lane pair, handed over by the lane that loaded it ----
       const int qi = qbase + grp;
       const bool qok = grp < qcount;
+      const float qpx = __shfl(sp.x, grp), qpy = __shfl(sp.y, grp), qpz = __shfl(sp.z, grp);
+      const int jp = __shfl(j_old, grp);
+      float4 bpo;
+      bpo.x = __shfl(bp_old.x, grp); bpo.y = __shfl(bp_old.y, grp); bpo.z = __shfl(bp_old.z, grp); bpo.w = 0.f;
       float qx = 0.f, qy = 0.f, qz = 0.f;
       int cx = 0, cy = 0, cz = 0;
       if (qok) {
-        const float4 qp = a.qpts[qi];
         // Eigen 4x4 * 4-vector in float: ((c0*x + c1*y) + c2*z) + c3*1
-        qx = ((Tf[0] * qp.x + Tf[1] * qp.y) + Tf[2] * qp.z) + Tf[3];
-        qy = ((Tf[4] * qp.x + Tf[5] * qp.y) + Tf[6] * qp.z) + Tf[7];
-        qz = ((Tf[8] * qp.x + Tf[9] * qp.y) + Tf[10] * qp.z) + Tf[11];
+        qx = ((Tf[0] * qpx + Tf[1] * qpy) + Tf[2] * qpz) + Tf[3];
+        qy = ((Tf[4] * qpx + Tf[5] * qpy) + Tf[6] * qpz) + Tf[7];
+        qz = ((Tf[8] * qpx + Tf[9] * qpy) + Tf[10] * qpz) + Tf[11];
         cell_coords(g, qx, qy, qz, cx, cy, cz);
       }
       float best = 3.4028234664e38f;
@@ -469,38 +474,33 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       // Warm start: between two LM trials the pose moves little, so the previous correspondence is almost always still the
       // nearest neighbour.  It is a genuine target point, so taking it as the first candidate keeps the search exact (the
       // total order decides as before) - but every row and every window is pruned against a tight bound from the start.
-      if (qok && st->hot.have_lin) {
-        const int jp = corr_old[qi];
-        if (jp >= 0) {
-          best = sqdist(qx, qy, qz, a.tgt[jp]);
-          pos = jp;
-        }
+      if (qok && jp >= 0) {
+        best = sqdist(qx, qy, qz, bpo);
+        pos = jp;
       }
       NG_STAMP(2);
-      // ---- index the batch's region.  Its bounding box comes from the batch's precomputed AABB pushed through
-      //      the trial pose (no cross-lane reduction); a batch never leaves one Morton tile, so it is bounded. ----
-      int b0x, b0y, b0z, b1x, b1y, b1z;
-      {
-        const float* bb = a.batch_boxes + (size_t)batch * 6;
-        const float bcx = bb[0], bcy = bb[1], bcz = bb[2], bhx = bb[3], bhy = bb[4], bhz = bb[5];
-        const float mx = ((Tf[0] * bcx + Tf[1] * bcy) + Tf[2] * bcz) + Tf[3];
-        const float my = ((Tf[4] * bcx + Tf[5] * bcy) + Tf[6] * bcz) + Tf[7];
-        const float mz = ((Tf[8] * bcx + Tf[9] * bcy) + Tf[10] * bcz) + Tf[11];
-        const float pad = 1e-3f * g.h;
-        const float ex = (fabsf(Tf[0]) * bhx + fabsf(Tf[1]) * bhy) + fabsf(Tf[2]) * bhz + pad + 4e-6f * (fabsf(mx) + bhx + bhy + bhz);
-        const float ey = (fabsf(Tf[4]) * bhx + fabsf(Tf[5]) * bhy) + fabsf(Tf[6]) * bhz + pad + 4e-6f * (fabsf(my) + bhx + bhy + bhz);
-        const float ez = (fabsf(Tf[8]) * bhx + fabsf(Tf[9]) * bhy) + fabsf(Tf[10]) * bhz + pad + 4e-6f * (fabsf(mz) + bhx + bhy + bhz);
-        cell_coords(g, mx - ex, my - ey, mz - ez, b0x, b0y, b0z);
-        cell_coords(g, mx + ex, my + ey, mz + ez, b1x, b1y, b1z);
-      }
-      int X0 = 0, Y0 = 0, Z0 = 0, XS = 1, wy = 1, grow = 0, nlive = 0;
+      // ---- rows beyond ring 1 are served from a LIST of the non-empty rows of the batch's region; only batches that looked
+      //      beyond ring 1 in the previous pass (or have no previous pass) pay for it.  The region's bounding box comes from
+      //      the batch's precomputed AABB pushed through the trial pose; a batch never leaves one Morton tile. ----
+      int Y0 = 0, Z0 = 0, wy = 1, grow = 0, nlive = 0;
+      int b0x = 0, b0y = 0, b0z = 0, b1x = 0, b1y = 0, b1z = 0;
       bool listed = false;
-      if (a.stage_grow >= 1) {
-        int rows;
-        // Most batches never look beyond ring 1 (and a batch that did not in the last pass will hardly do so now: the pose
-        // moves little): list only the rows of ring 1 for them, a quarter of the region.
-        const int grow_top = (!st->hot.have_lin || a.batch_far[batch] != 0) ? a.stage_grow : 1;
-        for (grow = grow_top;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
+      if (a.stage_grow >= 2 && (!have_prev || a.batch_far[batch] != 0)) {  // wave-uniform
+        {
+          const float* bb = a.batch_boxes + (size_t)batch * 6;
+          const float bcx = bb[0], bcy = bb[1], bcz = bb[2], bhx = bb[3], bhy = bb[4], bhz = bb[5];
+          const float mx = ((Tf[0] * bcx + Tf[1] * bcy) + Tf[2] * bcz) + Tf[3];
+          const float my = ((Tf[4] * bcx + Tf[5] * bcy) + Tf[6] * bcz) + Tf[7];
+          const float mz = ((Tf[8] * bcx + Tf[9] * bcy) + Tf[10] * bcz) + Tf[11];
+          const float pad = 1e-3f * g.h;
+          const float ex = (fabsf(Tf[0]) * bhx + fabsf(Tf[1]) * bhy) + fabsf(Tf[2]) * bhz + pad + 4e-6f * (fabsf(mx) + bhx + bhy + bhz);
+          const float ey = (fabsf(Tf[4]) * bhx + fabsf(Tf[5]) * bhy) + fabsf(Tf[6]) * bhz + pad + 4e-6f * (fabsf(my) + bhx + bhy + bhz);
+          const float ez = (fabsf(Tf[8]) * bhx + fabsf(Tf[9]) * bhy) + fabsf(Tf[10]) * bhz + pad + 4e-6f * (fabsf(mz) + bhx + bhy + bhz);
+          cell_coords(g, mx - ex, my - ey, mz - ez, b0x, b0y, b0z);
+          cell_coords(g, mx + ex, my + ey, mz + ez, b1x, b1y, b1z);
+        }
+        int rows, X0 = 0, XS = 1;
+        for (grow = a.stage_grow;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
           X0 = max(b0x - grow, 0);
           Y0 = max(b0y - grow, 0);
           Z0 = max(b0z - grow, 0);
@@ -508,19 +508,19 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
           XS = X1 - X0 + 1;
           wy = Y1 - Y0 + 1;
           rows = wy * (Z1 - Z0 + 1);
-          if ((rows <= kStageRows && XS <= kStageXs) || grow == 1) break;
+          if ((rows <= kStageRows && XS <= kStageXs) || grow == 2) break;
         }
         if (rows <= kStageRows && XS <= kStageXs) {
           // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target, and the
           // row's ring distance from the batch box (rows are listed nearest ring first)
-          int rb[kStageRowsPerLane], rs[kStageRowsPerLane], rn[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane];
+          int rs[kStageRowsPerLane], rn[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane];
 #pragma unroll
           for (int k = 0; k < kStageRowsPerLane; ++k) {
             const int r = lane + 64 * k;
             const bool has = r < rows;
             const int ry = Y0 + r % wy, rz = Z0 + r / wy;
-            rb[k] = has ? (rz * g.ny + ry) * g.nx + X0 : 0;
-            const int sv = has ? a.tgt_cell_start[rb[k]] : 0, ev = has ? a.tgt_cell_start[rb[k] + XS] : 0;
+            const int rb = has ? (rz * g.ny + ry) * g.nx + X0 : 0;
+            const int sv = has ? a.tgt_cell_start[rb] : 0, ev = has ? a.tgt_cell_start[rb + XS] : 0;
             rs[k] = sv;
             rn[k] = ev - sv;
             rho[k] = max(max(b0y - ry, ry - b1y), max(max(b0z - rz, rz - b1z), 0));
@@ -533,19 +533,11 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
             for (int k = 0; k < kStageRowsPerLane; ++k) {
               const bool on = rn[k] > 0 && rho[k] == lev;
               const unsigned long long m = __ballot(on);
-              if (on) {
-                const int li = nlive + __popcll(m & ((1ull << lane) - 1ull));
-                S.live[li] = make_int4(ryz[k], rn[k], rs[k], 0);  // {y | z << 16, points, first point, -}
-                S.row_live[lane + 64 * k] = (unsigned short)li;
-              }
+              if (on) S.live[nlive + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(ryz[k], rn[k], rs[k], 0);  // {y | z << 16, points, first point, -}
               nlive += __popcll(m);
             }
           }
-#pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k)
-            if (rn[k] == 0 && lane + 64 * k < rows) S.row_live[lane + 64 * k] = 0xffffu;
           listed = true;
-          wave_lds_sync();
         }
       }
       NG_STAMP(3);
@@ -558,80 +550,100 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       }
       bool went_far = false;
       // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
-      // simply takes the unindexed path
+      // simply takes the unlisted path beyond ring 1
       const bool in_box = qok && listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
       unsigned int dbg_g1 = 0, dbg_g2 = 0;
       auto pack_key = [](float d, int p) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)p; };
-      if (listed) {  // wave-uniform
-        if (in_box && sub == 0) {
-          ++nstaged;
-          S.qtab[grp] = make_float4(qx, qy, qz, 0.f);
-          S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
-        }
-        if (lane == 0) S.q_tail = 0, S.q_head = 0;
-        if (a.dbg_qstats && lane < 32) S.qstat[lane][0] = S.qstat[lane][1] = S.qstat[lane][2] = 0;
-        wave_lds_sync();
-        // ---- rings 0..1: one unit per non-empty row of the query's 3 x 3 (y,z) window that its (y,z) gap does not rule out ----
-        if (in_box) {
-          const float lim = fminf(best, a.gate_sq_f);
-          for (int order = sub; order < 9; order += G) {
-            const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
-            const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-            if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
-            if (S.row_live[(z - Z0) * wy + (y - Y0)] == 0xffff) continue;
-            if (row_gap_sq(g, y, z, cy, cz, qy, qz) > lim) continue;
-            S.units[atomicAdd(&S.q_tail, 1)] = grp | (tt << 8);  // at most 32 x 9 units: fits
-          }
-        }
-        wave_lds_sync();
-        {
-          const int tail = S.q_tail;
-          for (;;) {
-            const int u = atomicAdd(&S.q_head, 1);
-            if (u >= tail) break;
-            const int unit = S.units[u], qs = unit & 31, tt = unit >> 8;
-            const float4 q = S.qtab[qs];
-            int ux, uy, uz;
-            cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
-            const int z = uz + tt / 3 - 1, y = uy + tt % 3 - 1;
-            const float gyz = row_gap_sq(g, y, z, uy, uz, q.y, q.z);
-            const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
-            float ub = __uint_as_float((unsigned int)(k0 >> 32));
-            int up = (int)(unsigned int)k0;
-            if (gyz > fminf(ub, a.gate_sq_f)) continue;
-            const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1, rowb = (z * g.ny + y) * g.nx;
-            const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
-            if (e0 <= s0) continue;
-            const float frac = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
-            const unsigned int c_before = ncand;
-            scan_global_outward(a.tgt, s0, e0, s0 + (int)(frac * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
-            atomicMin(&S.qkey[qs], pack_key(ub, up));
-            if (a.dbg_qstats) {
-              atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
-              atomicAdd(&S.qstat[qs][1], 1);
+      // ---- rings 0..1.  The 3 x 3 window of (y,z) rows around the query's cell; a row of it is the x-sorted run of the cells
+      //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
+      //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it).  Every
+      //      non-empty row becomes a UNIT {query, run, starting position} in an LDS queue; whichever lane is free pops the next
+      //      unit and walks it.  The walk starts at the previous correspondence when that lies in the run (the window is then
+      //      centred on the best candidate), else where qx sits inside its own cell (interpolated). ----
+      if (qok && sub == 0) {
+        if (in_box) ++nstaged;
+        S.qtab[grp] = make_float4(qx, qy, qz, 0.f);
+        S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
+      }
+      if (lane == 0) S.q_tail = 0, S.q_head = 0;
+      if (a.dbg_qstats && lane < 32) S.qstat[lane][0] = S.qstat[lane][1] = S.qstat[lane][2] = 0;
+      wave_lds_sync();
+      if (qok) {
+        const float lim = fminf(best, a.gate_sq_f);
+        constexpr int kRowsPerLane = (9 + G - 1) / G;
+        struct alignas(4) Bounds4 { int v[4]; };
+        Bounds4 bnd[kRowsPerLane];
+        float gap[kRowsPerLane];
+        int code[kRowsPerLane];
+#pragma unroll
+        for (int k = 0; k < kRowsPerLane; ++k) {
+          const int order = sub + k * G;  // nearest rows first: the own row, its 4 edge neighbours, the 4 corners
+          const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
+          const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
+          code[k] = -1;
+          gap[k] = 0.f;
+          if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
+            if (gap[k] <= lim) {
+              code[k] = tt;
+              bnd[k] = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + ((z * g.ny + y) * g.nx + cx - 1));  // starts of cells cx-1, cx, cx+1, cx+2
             }
           }
         }
-        wave_lds_sync();
-        if (in_box) {
-          const unsigned long long k1 = S.qkey[grp];
-          best = __uint_as_float((unsigned int)(k1 >> 32));
-          pos = (int)(unsigned int)k1;
+        const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
+#pragma unroll
+        for (int k = 0; k < kRowsPerLane; ++k) {
+          if (code[k] < 0) continue;
+          const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
+          if (e0 <= s0) continue;
+          const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
+          const int slot = atomicAdd(&S.q_tail, 1);  // at most 32 x 9 units: fits
+          S.unit_q[slot] = grp | (code[k] << 5) | (min(max(m - s0, 0), (1 << 22) - 1) << 9);
+          S.unit_s[slot] = s0;
+          S.unit_e[slot] = e0;
+          S.unit_g[slot] = gap[k];
         }
       }
-      if (qok && !in_box) nn_ring1_global<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, sub, best, pos, ncand);
+      wave_lds_sync();
+      {
+        const int tail = S.q_tail;
+        for (;;) {
+          const int u = atomicAdd(&S.q_head, 1);
+          if (u >= tail) break;
+          const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
+          const float gyz = S.unit_g[u];
+          const float4 q = S.qtab[qs];
+          const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
+          float ub = __uint_as_float((unsigned int)(k0 >> 32));
+          int up = (int)(unsigned int)k0;
+          if (gyz > fminf(ub, a.gate_sq_f)) continue;
+          const unsigned int c_before = ncand;
+          scan_global_outward(a.tgt, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          atomicMin(&S.qkey[qs], pack_key(ub, up));
+          if (a.dbg_qstats) {
+            atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
+            atomicAdd(&S.qstat[qs][1], 1);
+          }
+        }
+      }
+      wave_lds_sync();
+      if (qok) {
+        const unsigned long long k1 = S.qkey[grp];
+        best = __uint_as_float((unsigned int)(k1 >> 32));
+        pos = (int)(unsigned int)k1;
+      }
       NG_STAMP(4);
       float bound1 = 0.f;
       if (qok) {
         bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-        went_far = !in_box || !(best <= bound1 || bound1 >= a.gate_sq_f);
+        went_far = !(best <= bound1 || bound1 >= a.gate_sq_f);
       }
       const unsigned int dbg_c1 = ncand;
       unsigned int dbg_rows = 0;
       // ---- rings 2..grow: units for the listed rows (nearest ring first) that can still hold a closer point, in rounds of
       //      kUnitCap; between rounds every query picks up what its units found, which prunes its remaining rows ----
-      const bool need_far = in_box && grow >= 2 && went_far;
-      if (listed && grow >= 2 && __any(need_far)) {  // wave-uniform
+      const bool need_far = in_box && went_far;
+      if (listed && __any(need_far)) {  // wave-uniform
         int li = sub;
         bool more = need_far;
         for (;;) {
@@ -644,7 +656,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
               if (row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz) > lim) continue;
               const int slot = atomicAdd(&S.q_tail, 1);
               if (slot >= kUnitCap) break;  // this row waits for the next round
-              S.units[slot] = grp | (li << 8);
+              S.unit_q[slot] = grp | (li << 5);
               ++dbg_rows;
             }
             more = li < nlive;
@@ -655,8 +667,8 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
             for (;;) {
               const int u = atomicAdd(&S.q_head, 1);
               if (u >= tail) break;
-              const int unit = S.units[u], qs = unit & 31;
-              const int4 rec = S.live[unit >> 8];
+              const int unit = S.unit_q[u], qs = unit & 31;
+              const int4 rec = S.live[unit >> 5];
               const float4 q = S.qtab[qs];
               int ux, uy, uz;
               cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
