@@ -248,7 +248,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
-  DevBuf dbg, dbg_q, grp_order, grp_cost, batch_far;
+  DevBuf dbg, dbg_q, dbg_s, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
   DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
@@ -694,6 +694,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.max_trace_rows = max_rows;
   s.mode = 0;
   s.sums_out = nullptr;
+  s.dbg_stamps = nullptr;
   c.lanes = lanes;
   c.nblocks = nblocks;
   h->stats.lanes_per_query = lanes;
@@ -798,6 +799,11 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)c.nblocks * 4 * 16 * sizeof(unsigned long long), h->stream));
     c.pa.dbg_stamps = h->dbg.as<unsigned long long>();
   }
+  if (std::getenv("NGICP_DEBUG_SOLVE")) {  // diagnostic only: s_memtime stamps of the last solver launch, printed after the align
+    h->dbg_s.ensure(8 * sizeof(unsigned long long));
+    HIP_TRY(hipMemsetAsync(h->dbg_s.p, 0, 8 * sizeof(unsigned long long), h->stream));
+    c.sa.dbg_stamps = h->dbg_s.as<unsigned long long>();
+  }
   const char* qstat_path = std::getenv("NGICP_DEBUG_QSTATS");  // diagnostic only: per-query search statistics of the last pass
   if (qstat_path) {
     h->dbg_q.ensure((size_t)c.pa.n_src * sizeof(int4));
@@ -849,6 +855,12 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       std::fwrite(hs.data(), sizeof(unsigned long long), hs.size(), f);
       std::fclose(f);
     }
+  }
+  if (c.sa.dbg_stamps) {
+    unsigned long long ts[8];
+    HIP_TRY(hipMemcpy(ts, h->dbg_s.p, sizeof(ts), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "k_lm_solve stamps (cycles since entry): loads issued %llu, reduced %llu, state in registers %llu, lm_advance %llu, accept path %llu, stored %llu\n",
+                 ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[4] - ts[0], ts[5] - ts[0], ts[6] - ts[0]);
   }
   if (qstat_path) {
     std::vector<int> hq((size_t)c.pa.n_src * 4);

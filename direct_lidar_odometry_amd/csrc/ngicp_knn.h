@@ -3,7 +3,7 @@
 // impl/nanoflann_impl.hpp:1230-1250,1355-1418) and NanoGICP::calculate_covariances
 // (impl/nano_gicp_impl.hpp:300-357).
 //
-// Exactness: rings of cells around the query cell are scanned until the k-th best squared
+// Exactness: rings of cells around the query cell are searched until the k-th best squared
 // distance is <= the squared distance to the nearest unexplored cell face (eps = 0, like the
 // reference).  Distances are float32 ((dx*dx + dy*dy) + dz*dz, no FMA: this TU is compiled with
 // -ffp-contract=off) exactly as impl/nanoflann_impl.hpp:441-449.  Ties are broken by visiting
@@ -94,73 +94,19 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const floa
   return r;
 }
 
-// scan one contiguous run of sorted points, eight loads in flight per round trip (one load at a time made the covariance
-// kernel purely latency-bound: ~650 dependent round trips per point).  The tail of the run repeats its last point; a repeat
-// is never inserted (j-th candidate only counts while p + j < e).
-template <int K>
-__device__ __forceinline__ void scan_run(const float4* __restrict__ sorted, int s, int e, float qx, float qy, float qz, int k, TopK<K>& top, float& worst) {
-  for (int p = s; p < e; p += 8) {
-    float d[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = sqdist(qx, qy, qz, sorted[min(p + j, e - 1)]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (p + j < e && d[j] < worst) {
-        top.insert(d[j], p + j);
-        worst = top.kth(k);
-      }
-    }
-  }
-}
-
-// Exact kNN of (qx,qy,qz) in an indexed cloud.  Result: top.id = SORTED positions, top.d ascending.
-// Ring expansion from ring r0 on (the list / `worst` hold what rings < r0 contributed; r0 = 0: a fresh search).
-template <int K>
-__device__ __forceinline__ void knn_rings(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                          int cx, int cy, int cz, int k, int r0, TopK<K>& top, float& worst) {
-  const int rmax = max(max(g.nx, g.ny), g.nz);
-  for (int r = r0; r <= rmax; ++r) {
-    const int z0 = max(cz - r, 0), z1 = min(cz + r, g.nz - 1);
-    const int y0 = max(cy - r, 0), y1 = min(cy + r, g.ny - 1);
-    const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
-    for (int z = z0; z <= z1; ++z) {
-      const bool zface = (z == cz - r) || (z == cz + r);
-      for (int y = y0; y <= y1; ++y) {
-        const int row = (z * g.ny + y) * g.nx;
-        if (zface || y == cy - r || y == cy + r) {
-          scan_run<K>(sorted, cell_start[row + xa], cell_start[row + xb + 1], qx, qy, qz, k, top, worst);
-        } else {
-          if (cx - r >= 0) scan_run<K>(sorted, cell_start[row + cx - r], cell_start[row + cx - r + 1], qx, qy, qz, k, top, worst);
-          if (cx + r <= g.nx - 1 && r > 0) scan_run<K>(sorted, cell_start[row + cx + r], cell_start[row + cx + r + 1], qx, qy, qz, k, top, worst);
-        }
-      }
-    }
-    if (worst <= unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r)) break;
-  }
-}
-
-template <int K>
-__device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                           int k, TopK<K>& top) {
-  top.init();
-  float worst = 3.4028234664e38f;
-  int cx, cy, cz;
-  cell_coords(g, qx, qy, qz, cx, cy, cz);
-  knn_rings<K>(g, sorted, cell_start, qx, qy, qz, cx, cy, cz, k, 0, top, worst);
-}
-
-// Exact k-NN of the cloud's OWN point at sorted position p (the covariance kernel's query): rings 0..1 are visited row by row
-// instead of cell by cell, and pruned:
-//   rows    a (y,z) row of the 3 x 3 window is one x-sorted run over the cells cx-1..cx+1.  The query's own row comes first,
-//           walked outward from p itself: the list fills with the nearest points of the run, and from then on the k-th best
-//           distance (`worst`) bounds everything else.  (A list-based bound only exists once the list holds k entries: until
-//           then `worst` is FLT_MAX and nothing is pruned.)  The other eight rows are skipped when their (y,z) gap alone
-//           reaches `worst`;
-//   walk    eight points per round trip, right then left of the starting position, each side only while |dx|^2 + gap can
-//           still beat `worst`;
-//   rings   if the k-th best is not provably exact after ring 1 (unexplored_bound_sq), the ring search continues at ring 2.
-// Every position is visited at most once (no duplicates in the list).  Ties: first visited stays in front (strict '<'), as in
-// knn_search; the visiting order differs, so among EXACTLY equal distances another index may be kept (SURVEY.md §7 "Ties").
+// Exact k-NN of (qx,qy,qz) in an indexed cloud, row by row.  Result: sorted positions, distances ascending.
+//   rings   rings of cells around the query's cell are visited until the k-th best squared distance (`worst`) is <= the squared
+//           distance to the nearest unexplored cell face (unexplored_bound_sq: eps = 0, like the reference);
+//   rows    rings 0..1 are the 3 x 3 window of (y,z) rows, each the x-sorted run of the cells cx-1..cx+1; ring r >= 2 adds the
+//           rows on the frame of the (2r+1)^2 window (runs cx-r..cx+r) and, for the rows inside the frame, the two end cells
+//           cx-r and cx+r.  A row or cell whose gap to the query alone reaches `worst` is skipped without a memory access.
+//           (A list-based bound only exists once the list holds k entries: until then `worst` is FLT_MAX and nothing is pruned.)
+//   walk    a run is walked outward from a starting position (the query point itself when it belongs to the cloud: p >= 0; else
+//           where qx sits in the run, interpolated), eight points per round trip, right then left, each side only while
+//           |dx|^2 + gap can still beat `worst`.
+// Every position is visited at most once (no duplicates in the list).  Ties: the first visited stays in front (strict '<'), like
+// KNNResultSet::addPoint (impl/nanoflann_impl.hpp:184-211); the visiting order is not a kd-tree's, so among EXACTLY equal
+// distances another index may be kept (SURVEY.md §7 "Ties").
 template <int K>
 __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, int s, int e, int m, float qx, float qy, float qz, float gap, int k, TopK<K>& top,
                                              float& worst) {
@@ -198,30 +144,48 @@ __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, 
 }
 
 template <int K>
-__device__ __forceinline__ void knn_self(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, int p, const float4 q, int k,
-                                         TopK<K>& top) {
+__device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
+                                           int p, int k, TopK<K>& top) {
   top.init();
   float worst = 3.4028234664e38f;
   int cx, cy, cz;
-  cell_coords(g, q.x, q.y, q.z, cx, cy, cz);
-  const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-  {
-    const int row = (cz * g.ny + cy) * g.nx;
-    knn_walk_row<K>(sorted, cell_start[row + xa], cell_start[row + xb + 1], p, q.x, q.y, q.z, 0.f, k, top, worst);
+  cell_coords(g, qx, qy, qz, cx, cy, cz);
+  const int rmax = max(max(g.nx, g.ny), g.nz);
+  for (int r = 1; r <= rmax + 1; ++r) {  // r = 1 stands for rings 0 and 1 together
+    if (r >= 2 && worst <= unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r - 1)) break;
+    const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
+    const float frac = fminf(fmaxf((qx - (g.ox + (float)xa * g.h)) / ((float)(xb + 1 - xa) * g.h), 0.f), 1.f);
+    // lower bounds of |dx| to the two end cells of an inner row (cells cx-r and cx+r)
+    const float xl = fmaxf(qx - (g.ox + (float)(cx - r + 1) * g.h) - g.slack, 0.f), xr = fmaxf((g.ox + (float)(cx + r) * g.h) - qx - g.slack, 0.f);
+    const int side = 2 * r + 1;
+    for (int t = 0; t < side * side; ++t) {
+      const int tt = r > 1 ? t : (t == 0 ? 4 : (t <= 4 ? t - 1 : t));  // rings 0..1: the query's own row first
+      const int dz = tt / side - r, dy = tt % side - r;
+      const int y = cy + dy, z = cz + dz;
+      if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+      const float gap = row_gap_sq(g, y, z, cy, cz, qy, qz);
+      if (gap >= worst) continue;
+      const int row = (z * g.ny + y) * g.nx;
+      const bool full = r == 1 || dz == -r || dz == r || dy == -r || dy == r;  // else an inner row: only its two end cells are new
+      for (int u = 0; u < (full ? 1 : 2); ++u) {
+        int c0, c1, m_hint;  // cells [c0, c1] of the row; where to start (0: interpolate, 1: the run's last point, 2: its first)
+        if (full) {
+          c0 = xa; c1 = xb; m_hint = 0;
+        } else if (u == 0) {
+          if (cx - r < 0 || xl * xl + gap >= worst) continue;
+          c0 = c1 = cx - r; m_hint = 1;
+        } else {
+          if (cx + r > g.nx - 1 || xr * xr + gap >= worst) continue;
+          c0 = c1 = cx + r; m_hint = 2;
+        }
+        const int s = cell_start[row + c0], e = cell_start[row + c1 + 1];
+        if (e <= s) continue;
+        int m = m_hint == 1 ? e - 1 : (m_hint == 2 ? s : s + (int)(frac * (float)(e - s)));
+        if (r == 1 && tt == 4 && p >= 0) m = p;  // the query is a point of this cloud: start at itself
+        knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst);
+      }
+    }
   }
-  const float frac = fminf(fmaxf((q.x - (g.ox + (float)xa * g.h)) / ((float)(xb + 1 - xa) * g.h), 0.f), 1.f);
-  for (int t = 0; t < 9; ++t) {
-    const int y = cy + t % 3 - 1, z = cz + t / 3 - 1;
-    if (t == 4 || y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
-    const float gap = row_gap_sq(g, y, z, cy, cz, q.y, q.z);
-    if (gap >= worst) continue;
-    const int row = (z * g.ny + y) * g.nx;
-    const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
-    if (e <= s) continue;
-    knn_walk_row<K>(sorted, s, e, s + (int)(frac * (float)(e - s)), q.x, q.y, q.z, gap, k, top, worst);
-  }
-  if (worst <= unexplored_bound_sq(g, q.x, q.y, q.z, cx, cy, cz, 1)) return;
-  knn_rings<K>(g, sorted, cell_start, q.x, q.y, q.z, cx, cy, cz, k, 2, top, worst);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,7 +201,7 @@ __global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ 
   if (i >= n) return;
   const float4 q = sorted[i];
   TopK<K> top;
-  knn_self<K>(g, sorted, cell_start, i, q, k, top);
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top);
 
   // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k
   double mx = 0, my = 0, mz = 0;
@@ -315,7 +279,7 @@ __global__ void __launch_bounds__(128) k_knn_queries(const float4* __restrict__ 
   if (i >= nq) return;
   const float4 q = queries[i];
   TopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, k, top);
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top);
   static_for<0, K>([&](auto S) {
     if (S.value < k) {
       const int pos = top.template id<S.value>();

@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       // whatever lies beyond the listed rings: rare, per query
       const unsigned int c_before_shells = ncand;
       if (qok) nn_shells<G>(g, a.tgt, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, need_far ? grow : 1, best, pos, ncand);
-      if (a.dbg_qstats && listed) {  // wave-uniform
+      if (a.dbg_qstats) {  // wave-uniform
         if (qok) atomicAdd(&S.qstat[grp][2], (int)(ncand - c_before_shells));
         wave_lds_sync();
         if (qok && sub == 0) a.dbg_qstats[qi] = make_int4(S.qstat[grp][0], S.qstat[grp][1], S.qstat[grp][2], (went_far ? 1 : 0) | (in_box ? 2 : 0) | (pos >= 0 ? 4 : 0));
@@ -866,6 +866,7 @@ struct SolveArgs {
   double* sums_out;        // optional [kPartialStride] reduced sums (29 sums + 2 counters + 1 pad)
   int* grp_order;          // [nblocks] out: groups sorted by measured cost, heaviest first (mode 0 only), or null
   const int* grp_cost;     // [nblocks] in: duration of each group's block in the pass just finished
+  unsigned long long* dbg_stamps;  // diagnostic only: [8] s_memtime stamps of the last launch, or null
 };
 
 __device__ __forceinline__ bool is_converged_dev(const Pose& d, double rot_eps, double trans_eps) {  // impl/lsq_registration_impl.hpp:118-127
@@ -998,6 +999,11 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
   if (a.mode == 0 && st->hot.done) return;
+#define NG_SSTAMP(k)                                                                 \
+  do {                                                                               \
+    if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  NG_SSTAMP(0);
   // the state the serial lane will work on: fetched now by the whole block (one coalesced round trip that overlaps the
   // partial loads) instead of by lane 0 after the reduction, where it would be a dependent round trip on the critical path
   __shared__ int hot_copy[(sizeof(LmHot) + 3) / 4];
@@ -1024,6 +1030,7 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
     for (int v = 0; v < kNumSlots; ++v) acc[v] = (acc[v] + p0[v]) + p1[v];  // same order as one column at a time
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  NG_SSTAMP(1);
   {
     double* tile = red_tile[wave];  // [64][33]
 #pragma unroll
@@ -1048,6 +1055,7 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
     sums[v] = v < kNumSlots ? ((wsum[0][v] + wsum[1][v]) + wsum[2][v]) + wsum[3][v] : 0.0;
   }
   __syncthreads();
+  NG_SSTAMP(2);
   if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
   if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
   if (order_it && wave == 1) {
@@ -1104,7 +1112,9 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
 
   const LmConfig& cfg = a.cfg;
   const bool gn = cfg.optimizer == 0;
+  NG_SSTAMP(3);
   const bool accepted = lm_advance(L, cfg, sums, a.trace, a.max_trace_rows);
+  NG_SSTAMP(4);
   if (accepted) {
 #pragma unroll
     for (int i = 0; i < 36; ++i) st->final_hessian[i] = L.H[i];
@@ -1133,6 +1143,7 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
       }
     }
   }
+  NG_SSTAMP(5);
   if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
   if (!L.done) {
 #pragma unroll
@@ -1143,6 +1154,8 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
     }
   }
   st->hot = L;
+  NG_SSTAMP(6);
+#undef NG_SSTAMP
 }
 
 // map correspondences (sorted source slot -> sorted target position) back to ORIGINAL indices

@@ -39,6 +39,18 @@ for f in (0.01, 0.05, 0.1, 0.25):
     print(f"  heaviest {f:.0%} of queries hold {cs[int(len(srt) * f)]:.1%} of the candidates")
 um = (fl & 4) == 0
 print("unmatched queries:", um.mean(), "their mean cand", tot[um].mean() if um.any() else 0, "share of all cand", tot[um].sum() / tot.sum())
+os.environ["NGICP_DEBUG_SOLVE"] = "1"
+g.align(w.guess)
+del os.environ["NGICP_DEBUG_SOLVE"]
+for k in (10, 20):
+    e = NanoGICP(); e.setCorrespondenceRandomness(k)
+    for name, cloud in (("source", w.source), ("target", w.target)):
+        e.setInputSource(cloud)
+        ts = []
+        for _ in range(4):
+            e.calculateSourceCovariances(); ts.append(e.stats()["covariance_ms"])
+        print(f"covariances k={k} {name} n={len(cloud)}: {min(ts[1:]):.3f} ms")
+    e.close()
 os.environ["NGICP_DEBUG_STAMPS"] = sf
 g.align(w.guess)
 del os.environ["NGICP_DEBUG_STAMPS"]
