@@ -666,7 +666,6 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.batch_far = h->batch_far.as<unsigned char>();
   a.st = h->state.as<LmState>();
   a.partials = h->partials.as<double>();
-  a.partial_pitch = nblocks;
   a.mode = 3;
   a.dbg_stamps = nullptr;
   a.dbg_qstats = nullptr;
@@ -687,7 +686,6 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.cfg.lm_init_lambda_factor = h->p.lm_init_lambda_factor;
   s.partials = a.partials;
   s.nblocks = nblocks;
-  s.pitch = nblocks;
   s.grp_order = h->grp_order.as<int>();
   s.grp_cost = h->grp_cost.as<int>();
   s.trace = h->trace.as<double>();
@@ -1381,7 +1379,6 @@ int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* stream_or_nul
     c.sa.mode = 0;
     c.sa.partials = sums32_dev;  // one pre-reduced vector
     c.sa.nblocks = 1;
-    c.sa.pitch = 1;
     c.sa.grp_order = nullptr;  // the vector is one pre-reduced column, not per-group partials
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
     LmState* dst = h->state.as<LmState>();

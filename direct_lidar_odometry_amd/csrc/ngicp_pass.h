@@ -91,8 +91,7 @@ struct PassArgs {
   unsigned char* batch_far; // [n_batches] 1 if some query of the batch looked beyond its ring 1 in the previous pass: only then
                             // are the outer rings of the batch region listed (a wrong guess costs time, not exactness)
   LmState* st;
-  double* partials;         // [kNumSlots][partial_pitch], slot-major
-  int partial_pitch;        // >= number of groups
+  double* partials;         // [n_groups][kNumSlots], group-major: a block stores its 32 sums as one 256-byte row
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
   int stage_grow;           // rings around the batch box that the LDS row list covers (0: no list, search unindexed)
   unsigned long long* dbg_stamps;  // diagnostic only: [wave][16] s_memtime stamps, or null
@@ -220,8 +219,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // more than it saved - the 8 MB target lives in L2 / Infinity Cache, a walk touches 8-16 points of a row, and the LDS
 // the copies needed held occupancy at 8 waves per CU.  What pays is the row LIST (which rows exist, where they start)
 // and 12 waves per CU hiding the walks' latency.
-// Partial sums are stored per GROUP, slot-major ([slot][group]), so that (a) the solver reads them coalesced and (b)
-// the result does not depend on the order in which the groups are launched - which the solver sorts by measured cost.
+// Partial sums are stored per GROUP ([group][slot]: one 256-byte row per block), so that the result does not depend on the
+// order in which the groups are launched - which the solver sorts by measured cost.
 constexpr int kStageRowsPerLane = 4;
 constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows of a batch region
 constexpr int kStageXs = 20;         // cells per row of the region
@@ -841,7 +840,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   NG_STAMP(9);
   if (threadIdx.x < kNumSlots) {
     const int v = threadIdx.x;
-    a.partials[(size_t)v * a.partial_pitch + group] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
+    a.partials[(size_t)group * kNumSlots + v] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
   }
   if (a.grp_cost && threadIdx.x == 0) a.grp_cost[group] = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
 }
@@ -852,14 +851,14 @@ __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r 
 
 // --- the solver ----------------------------------------------------------------------------------
 constexpr int kMaxOrderGroups = 8192;  // launch-order sort: groups whose costs fit the solver's LDS
-constexpr int kSolveThreads = 256;  // 4 waves: keeps the full VGPR budget for the serial lane
+constexpr int kSolveThreads = 512;  // 8 waves = 2 per SIMD: the serial lane keeps a 256-VGPR budget, the reduction gets 512 loaders
+constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (thread = 16 slot pairs x 32 group subsets)
 
 struct SolveArgs {
   LmState* st;
   LmConfig cfg;
-  const double* partials;  // [kNumSlots][pitch] slot-major (pitch == 1: one pre-reduced vector)
+  const double* partials;  // [nblocks][kNumSlots] group-major (nblocks == 1: one pre-reduced vector)
   int nblocks;
-  int pitch;
   double* trace;           // [max_rows][8]
   int max_trace_rows;
   int mode;                // 0: LM/GN state machine; 1: reduce -> H/b/y0 (linearize hook); 2: reduce -> y0 = yi (error hook); 3: reduce only
@@ -992,9 +991,8 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
 }
 
 __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
-  __shared__ double wsum[kSolveThreads / 64][kPartialStride];
+  __shared__ double wsum[kSolveSubs][kPartialStride];
   __shared__ double sums[kPartialStride];
-  __shared__ double red_tile[kSolveThreads / 64][64 * 33];
   __shared__ int ord_cnt[16], ord_pos[16], ord_max;
   __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
@@ -1006,53 +1004,48 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   NG_SSTAMP(0);
   // the state the serial lane will work on: fetched now by the whole block (one coalesced round trip that overlaps the
   // partial loads) instead of by lane 0 after the reduction, where it would be a dependent round trip on the critical path
-  __shared__ int hot_copy[(sizeof(LmHot) + 3) / 4];
-  for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) hot_copy[w] = reinterpret_cast<const int*>(&st->hot)[w];
+  // The serial lane then works on this LDS image in place (a register-resident copy needs ~260 VGPRs: it spills at two waves
+  // per SIMD), and wave 0 stores it back with one coalesced pass.
+  __shared__ LmHot L;
+  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
+  for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) reinterpret_cast<int*>(&L)[w] = reinterpret_cast<const int*>(&st->hot)[w];
   const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
   if (order_it)  // the groups' measured costs, for the launch order built further down (visible after the barriers below)
     for (int gi = threadIdx.x; gi < a.nblocks; gi += kSolveThreads) ord_cost[gi] = a.grp_cost[gi];
 
-  // ---- deterministic reduction of the block partials: all loads of a step in flight together, then a transpose
-  //      through LDS (lane v adds column v in fixed order) instead of a butterfly of 64-bit LDS-crossbar shuffles ----
-  double acc[kNumSlots];
-#pragma unroll
-  for (int v = 0; v < kNumSlots; ++v) acc[v] = 0.0;
-  for (int b = threadIdx.x; b < a.nblocks; b += 2 * kSolveThreads) {  // two columns per step: 64 loads in flight per thread
-    const int b2 = b + kSolveThreads;
-    const bool has2 = b2 < a.nblocks;
-    double p0[kNumSlots], p1[kNumSlots];
-#pragma unroll
-    for (int v = 0; v < kNumSlots; ++v) {
-      p0[v] = a.partials[(size_t)v * a.pitch + b];
-      p1[v] = has2 ? a.partials[(size_t)v * a.pitch + b2] : 0.0;
-    }
-#pragma unroll
-    for (int v = 0; v < kNumSlots; ++v) acc[v] = (acc[v] + p0[v]) + p1[v];  // same order as one column at a time
-  }
+  // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
+  //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, 32 sixteen-byte loads in flight per step (one step
+  //      covers 1024 groups: the whole c3 grid in a single memory round trip); the 32 subset sums of a slot are then added
+  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass. ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  NG_SSTAMP(1);
   {
-    double* tile = red_tile[wave];  // [64][33]
+    const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
+    const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
+    double a0 = 0.0, a1 = 0.0;
+    for (int g0 = sb; g0 < a.nblocks; g0 += kSolveSubs * 32) {
+      double2 p[32];
 #pragma unroll
-    for (int v = 0; v < kNumSlots; ++v) tile[lane * 33 + v] = acc[v];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < kNumSlots) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four interleaved chains: (l mod 4) fixed order
-      for (int l = 0; l < 64; l += 4) {
-        s0 += tile[(l + 0) * 33 + lane];
-        s1 += tile[(l + 1) * 33 + lane];
-        s2 += tile[(l + 2) * 33 + lane];
-        s3 += tile[(l + 3) * 33 + lane];
+      for (int j = 0; j < 32; ++j) {
+        const int gi = g0 + j * kSolveSubs;
+        p[j] = gi < a.nblocks ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
       }
-      wsum[wave][lane] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        a0 += p[j].x;
+        a1 += p[j].y;
+      }
     }
+    NG_SSTAMP(1);
+    wsum[sb][2 * vp] = a0;
+    wsum[sb][2 * vp + 1] = a1;
   }
   __syncthreads();
   if (threadIdx.x < kPartialStride) {
     const int v = threadIdx.x;
-    sums[v] = v < kNumSlots ? ((wsum[0][v] + wsum[1][v]) + wsum[2][v]) + wsum[3][v] : 0.0;
+    double t = 0.0;
+    if (v < kNumSlots)
+      for (int sb = 0; sb < kSolveSubs; ++sb) t += wsum[sb][v];
+    sums[v] = t;
   }
   __syncthreads();
   NG_SSTAMP(2);
@@ -1092,68 +1085,63 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
     for (int gi = lane; gi < a.nblocks; gi += 64) a.grp_order[atomicAdd(&ord_pos[ord_cost[gi]], 1)] = gi;
     if (lane == 0) st->order_valid = 1;
   }
-  if (threadIdx.x != 0) return;
-
-  LmHot L;  // private register copy
-  {
-    int* dstw = reinterpret_cast<int*>(&L);
-#pragma unroll
-    for (int w = 0; w < (int)(sizeof(LmHot) / 4); ++w) dstw[w] = hot_copy[w];
-  }
-  if (a.mode == 1) {  // linearize hook
-    adopt_new(L, sums);
-    st->hot = L;
-    return;
-  }
+  if (wave != 0) return;
   if (a.mode == 2) {  // compute_error hook
-    st->hot.y0 = sums[28];
+    if (lane == 0) st->hot.y0 = sums[28];
     return;
   }
-
-  const LmConfig& cfg = a.cfg;
-  const bool gn = cfg.optimizer == 0;
-  NG_SSTAMP(3);
-  const bool accepted = lm_advance(L, cfg, sums, a.trace, a.max_trace_rows);
-  NG_SSTAMP(4);
-  if (accepted) {
+  if (lane == 0) {
+    if (a.mode == 1) {  // linearize hook
+      adopt_new(L, sums);
+    } else {
+      const LmConfig& cfg = a.cfg;
+      const bool gn = cfg.optimizer == 0;
+      NG_SSTAMP(3);
+      const bool accepted = lm_advance(L, cfg, sums, a.trace, a.max_trace_rows);
+      NG_SSTAMP(4);
+      if (accepted) {
 #pragma unroll
-    for (int i = 0; i < 36; ++i) st->final_hessian[i] = L.H[i];
-    if (!gn) {
-      // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
-      const double den_dummy = 0.0;
-      (void)den_dummy;
-      double den = 0.0;
+        for (int i = 0; i < 36; ++i) st->final_hessian[i] = L.H[i];
+        if (!gn) {
+          // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
+          double den = 0.0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
-      const double rho = (L.y0 - sums[28]) / den;
-      L.x0 = L.xi;
-      const double q = 2 * rho - 1;
-      L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - q * q * q);
-      L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
-      L.iter += 1;
-      if (L.converged || L.iter >= cfg.max_iterations) {
-        L.done = 1;
-      } else {
-        // the speculative linearisation at xi (== new x0) becomes current
-        adopt_new(L, sums);
-        L.nr_iterations = L.iter;
-        L.nu = 2.0;
-        L.trial = 0;
-        make_trial(L, L.lambda);
+          for (int i = 0; i < 6; ++i) den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
+          const double rho = (L.y0 - sums[28]) / den;
+          L.x0 = L.xi;
+          const double q = 2 * rho - 1;
+          L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - q * q * q);
+          L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
+          L.iter += 1;
+          if (L.converged || L.iter >= cfg.max_iterations) {
+            L.done = 1;
+          } else {
+            // the speculative linearisation at xi (== new x0) becomes current
+            adopt_new(L, sums);
+            L.nr_iterations = L.iter;
+            L.nu = 2.0;
+            L.trial = 0;
+            make_trial(L, L.lambda);
+          }
+        }
+      }
+      NG_SSTAMP(5);
+      if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
+      if (!L.done) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) st->xi_f[r * 4 + c] = (float)L.xi.R[r * 3 + c];
+          st->xi_f[r * 4 + 3] = (float)L.xi.t[r];
+        }
       }
     }
   }
-  NG_SSTAMP(5);
-  if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
-  if (!L.done) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) st->xi_f[r * 4 + c] = (float)L.xi.R[r * 3 + c];
-      st->xi_f[r * 4 + 3] = (float)L.xi.t[r];
-    }
-  }
-  st->hot = L;
+  // wave 0 stores the state image back (lane 0's LDS writes are ordered before the other lanes' reads by the fence pair)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
   NG_SSTAMP(6);
 #undef NG_SSTAMP
 }
