@@ -251,7 +251,7 @@ struct ngicp {
   DevBuf dbg, dbg_q, dbg_s, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
-  DevBuf corr[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
+  DevBuf tpt[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_poll = nullptr;  // pinned: done flags
   LmState* pin_state = nullptr;  // pinned [2]: the state image an align uploads / the one it reads back (no staging copies)
@@ -622,7 +622,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   DeviceCloud& T = *h->tgt.dev;
   const size_t n = S.n;
   for (int i = 0; i < 2; ++i) {
-    h->corr[i].ensure(n * sizeof(int));
+    h->tpt[i].ensure(n * sizeof(float4));
     h->mahal[i].ensure(n * 6 * sizeof(double));
   }
   int lanes = h->lanes_per_query > 0 ? h->lanes_per_query : auto_lanes(n);
@@ -653,7 +653,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
   for (int i = 0; i < 2; ++i) {
-    a.corr[i] = h->corr[i].as<int>();
+    a.tpt[i] = h->tpt[i].as<float4>();
     a.mahal[i] = h->mahal[i].as<double>();
   }
   a.gate_sq = h->p.max_corr_dist * h->p.max_corr_dist;
@@ -1258,7 +1258,7 @@ int ngicp_get_correspondences(ngicp_t* h, int* corr_out, float* sqd_out) {
     h->knn_idx.ensure(n * sizeof(int));
     h->knn_d2.ensure(n * sizeof(float));
     LmState* dst = h->state.as<LmState>();
-    hipLaunchKernelGGL(k_corr_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->corr[st.hot.cur].as<int>(), h->src.dev->qpts.as<float4>(),
+    hipLaunchKernelGGL(k_corr_to_original, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->tpt[st.hot.cur].as<float4>(), h->src.dev->qpts.as<float4>(),
                        h->src.dev->pts(), h->tgt.dev->pts(), (int)n, h->knn_idx.as<int>(), sqd_out ? h->knn_d2.as<float>() : nullptr, dst->xi_f);
     HIP_TRY(hipMemcpyAsync(corr_out, h->knn_idx.p, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (sqd_out) HIP_TRY(hipMemcpyAsync(sqd_out, h->knn_d2.p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(256) k_tile_place(const float4* __restrict__ s
 }
 
 // The cell-sorted point array is framed by kSortedPad far-away sentinels on each side (see DeviceCloud::sorted).
-constexpr int kSortedPad = 16;
+constexpr int kSortedPad = 32;  // >= the widest walk window (NGICP_WALK_WINDOW) and >= 16 for the k-NN seed of k <= 32
 __global__ void k_fill_sentinels(float4* __restrict__ padded, int n) {
   const int t = threadIdx.x;  // 2 * kSortedPad threads
   const float far = 3.0e38f;  // squared distance overflows to +inf: never closer than anything

@@ -84,7 +84,8 @@ struct PassArgs {
   const int* tgt_cell_start;
   const double* cov_tgt;    // [n_tgt][6], target sorted order
   Grid grid;                // target grid
-  int* corr[2];             // [n_src] sorted target position or -1
+  float4* tpt[2];           // [n_src] the correspondence of each query: {x, y, z of the target point, bitcast(sorted target position or -1)}:
+                            // the next pass gets the warm start of its search and K4's target point in ONE load (no corr -> point chain)
   double* mahal[2];         // [n_src][6]
   double gate_sq;           // corr_dist_threshold_^2 (double, impl/nano_gicp_impl.hpp:195)
   float gate_sq_f;          // float upper bound of gate_sq for ring termination
@@ -230,6 +231,7 @@ constexpr int kStageMaxGrow = 6;
 #define NGICP_WALK_WINDOW 12
 #endif
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
+static_assert(kWalkWindow <= kSortedPad && kWalkWindow % 2 == 0, "walk windows may overhang the array by at most the sentinel frame");
 
 constexpr int kUnitCap = 288;         // queued (query, row) walks per round (ring 1 needs 32 queries x 9 rows)
 
@@ -387,9 +389,9 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
   const bool do_err = (a.mode & 1) && st->hot.have_lin;
   const bool do_lin = (a.mode & 2);
   const int cur = st->hot.cur, nxt = cur ^ 1;
-  const int* __restrict__ corr_old = a.corr[cur];
+  const float4* __restrict__ tpt_old = a.tpt[cur];
   const double* __restrict__ mahal_old = a.mahal[cur];
-  int* __restrict__ corr_new = a.corr[nxt];
+  float4* __restrict__ tpt_new = a.tpt[nxt];
   double* __restrict__ mahal_new = a.mahal[nxt];
   const Grid& g = a.grid;
 
@@ -434,7 +436,10 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mine) {
       sp = a.qpts[i];
-      if (have_prev) j_old = corr_old[i];  // K4's correspondence and the search's warm start
+      if (have_prev) {  // K4's correspondence and the search's warm start
+        bp_old = tpt_old[i];
+        j_old = __float_as_int(bp_old.w);
+      }
       if (do_err) {
         const double* M = mahal_old + (size_t)i * 6;
 #pragma unroll
@@ -445,7 +450,6 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 #pragma unroll
         for (int e = 0; e < 6; ++e) ca[e] = CA[e];
       }
-      if (j_old >= 0) bp_old = a.tgt[j_old];
     }
 
     if (do_lin && (a.mode & 8)) {  // DEBUG timing build: fake search result
@@ -728,7 +732,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 #pragma unroll
     for (int v = 0; v < kNumSums; ++v) acc[v] = 0.0;
     if ((a.mode & 16) && mine) {  // DEBUG timing build: skip the FP64 tail
-      corr_new[i] = mypos;
+      tpt_new[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(mypos));
       acc[27] += (double)mybest;
     } else if (mine) {
       const double ax = (double)sp.x, ay = (double)sp.y, az = (double)sp.z;
@@ -749,12 +753,13 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       if (do_lin) {
         const int pos = mypos;
         const bool valid = (pos >= 0) && ((double)mybest < a.gate_sq);  // impl/nano_gicp_impl.hpp:195
-        corr_new[i] = valid ? pos : -1;
+        if (!valid) tpt_new[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (valid) {
           ++nvalid;
           // Mahalanobis: (C_B + R C_A R^T)^-1  (impl/nano_gicp_impl.hpp:205-209)
           const double* CB = a.cov_tgt + (size_t)pos * 6;
           const float4 bp = a.tgt[pos];
+          tpt_new[i] = make_float4(bp.x, bp.y, bp.z, __int_as_float(pos));
           double rcr[6], M[6];
           rotate_sym(R, ca, rcr);
 #pragma unroll
@@ -1147,14 +1152,14 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
 }
 
 // map correspondences (sorted source slot -> sorted target position) back to ORIGINAL indices
-__global__ void __launch_bounds__(256) k_corr_to_original(const int* __restrict__ corr, const float4* __restrict__ qpts, const float4* __restrict__ src_sorted,
+__global__ void __launch_bounds__(256) k_corr_to_original(const float4* __restrict__ tpt, const float4* __restrict__ qpts, const float4* __restrict__ src_sorted,
                                                            const float4* __restrict__ tgt_sorted, int n, int* __restrict__ out_corr, float* __restrict__ out_sqd,
                                                            const float* __restrict__ xi_f) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 sp = qpts[i];
   const int o = __float_as_int(src_sorted[__float_as_int(sp.w)].w);
-  const int j = corr[i];
+  const int j = __float_as_int(tpt[i].w);
   out_corr[o] = j >= 0 ? __float_as_int(tgt_sorted[j].w) : -1;
   if (out_sqd) {
     float d = __builtin_inff();
