@@ -793,8 +793,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
 
   const char* stamp_path = std::getenv("NGICP_DEBUG_STAMPS");  // diagnostic only
   if (stamp_path) {
-    h->dbg.ensure((size_t)c.nblocks * 4 * 16 * sizeof(unsigned long long));
-    HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)c.nblocks * 4 * 16 * sizeof(unsigned long long), h->stream));
+    h->dbg.ensure((size_t)c.nblocks * 4 * kStampStride * sizeof(unsigned long long));
+    HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)c.nblocks * 4 * kStampStride * sizeof(unsigned long long), h->stream));
     c.pa.dbg_stamps = h->dbg.as<unsigned long long>();
   }
   if (std::getenv("NGICP_DEBUG_SOLVE")) {  // diagnostic only: s_memtime stamps of the last solver launch, printed after the align
@@ -847,7 +847,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   HIP_TRY(hipEventElapsedTime(&loop_ms, h->ev_a, h->ev_b));
 
   if (stamp_path) {
-    std::vector<unsigned long long> hs((size_t)c.nblocks * 4 * 16);
+    std::vector<unsigned long long> hs((size_t)c.nblocks * 4 * kStampStride);
     HIP_TRY(hipMemcpy(hs.data(), h->dbg.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(stamp_path, "wb")) {
       std::fwrite(hs.data(), sizeof(unsigned long long), hs.size(), f);

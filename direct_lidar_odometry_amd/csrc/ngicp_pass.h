@@ -95,7 +95,7 @@ struct PassArgs {
   double* partials;         // [n_groups][kNumSlots], group-major: a block stores its 32 sums as one 256-byte row
   int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
   int stage_grow;           // rings around the batch box that the LDS row list covers (0: no list, search unindexed)
-  unsigned long long* dbg_stamps;  // diagnostic only: [wave][16] s_memtime stamps, or null
+  unsigned long long* dbg_stamps;  // diagnostic only: [wave][kStampStride] s_memtime stamps + counters, or null
   int4* dbg_qstats;                // diagnostic only: per query {ring-1 candidates, ring-1 walks | far walks << 16, far + shell candidates, flags}, or null
 };
 
@@ -372,9 +372,10 @@ __device__ __forceinline__ void nn_shells(const Grid& g, const float4* __restric
   }
 }
 
+constexpr int kStampStride = 24;
 #define NG_STAMP(k)                                                                                   \
   do {                                                                                                \
-    if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * kStampStride + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
 template <int G>
@@ -545,7 +546,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       }
       NG_STAMP(3);
       if (a.dbg_stamps && lane == 0) {
-        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
+        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
         d[10] = (unsigned long long)(listed ? grow : 0);
         d[11] = (unsigned long long)nlive;
         d[12] = (unsigned long long)qcount;
@@ -608,11 +609,14 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
         }
       }
       wave_lds_sync();
+      NG_STAMP(16);
       {
         const int tail = S.q_tail;
+        unsigned int popped = 0;
         for (;;) {
           const int u = atomicAdd(&S.q_head, 1);
           if (u >= tail) break;
+          ++popped;
           const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
           const float gyz = S.unit_g[u];
           const float4 q = S.qtab[qs];
@@ -627,6 +631,12 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
             atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
             atomicAdd(&S.qstat[qs][1], 1);
           }
+        }
+        NG_STAMP(17);
+        if (a.dbg_stamps) {
+          unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
+          atomicMax(&d[18], (unsigned long long)popped);
+          if (lane == 0) d[19] = (unsigned long long)tail;
         }
       }
       wave_lds_sync();
@@ -706,7 +716,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       }
       NG_STAMP(5);
       if (a.dbg_stamps && qok) {
-        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * 16;
+        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
         atomicMax(&d[14], ((unsigned long long)(dbg_g2 & 0xffff) << 48) | ((unsigned long long)(dbg_g2 >> 16) << 32) | ((unsigned long long)dbg_rows << 16) | (ncand - dbg_c1));
         atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
       }

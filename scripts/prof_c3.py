@@ -7,6 +7,11 @@ from direct_lidar_odometry_amd.nano_gicp import NanoGICP
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 cfg = sys.argv[2] if len(sys.argv) > 2 else "c3"
 w = clouds.scan_to_submap(100_000, 5) if cfg == "c3" else (clouds.scan_to_scan(100_000) if cfg == "c2" else clouds.scan_to_submap(250_000, 8, shape="os1"))
+rot = float(os.environ.get("ROT_DEG", "0"))
+if rot:  # the same scene seen in a frame turned about z: are axis-aligned walls special for the index?
+    Rz = clouds.make_pose((0, 0, 0), (0, 0, rot))
+    w.source = clouds.transform_points(Rz, w.source); w.target = clouds.transform_points(Rz, w.target)
+    w.guess = (Rz @ w.guess.astype(np.float64) @ np.linalg.inv(Rz)).astype(np.float32)
 g = NanoGICP()
 g.setMaxCorrespondenceDistance(float(os.environ.get("NGICP_GATE", w.max_corr_dist)))
 g.setMaximumIterations(20); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)

@@ -1,5 +1,6 @@
 import sys, numpy as np
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16).astype(np.float64)
+raw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 24)
+a = raw.astype(np.float64)
 a = a[a[:, 0] > 0]
 t0 = a[:, 0].min()
 names = ["entry", "prologue loads", "query cells", "rows listed", "ring1 done", "far rows done", "shells done", "loop end", "reduce done", "barrier"]
@@ -34,3 +35,13 @@ for w in order:
     print(int(life[w]), [int(x) for x in d], int(g[w]), int(nl[w]), int(qc[w]), (int(bb[w]) & 255, (int(bb[w]) >> 8) & 255, (int(bb[w]) >> 16) & 255),
           "max-lane ring1: steps", x15 >> 48, "rows", (x15 >> 32) & 0xffff, "cand", x15 & 0xffffffff, "| far: steps", x14 >> 48, "walked", (x14 >> 32) & 0xffff, "rows", (x14 >> 16) & 0xffff, "cand", x14 & 0xffff)
 print("sum of wave lifetimes (to reduce-done):", life.sum(), " / 3072 slots =", life.sum() / 3072)
+
+# ring 1 in detail: [3] rows listed -> [16] units queued (bounds round trip + pushes) -> [17] queue drained -> [4]
+m = (a[:, 16] > 0) & (a[:, 17] > 0)
+for name, d in (("ring1: bounds + enqueue", a[m, 16] - a[m, 3]), ("ring1: drain queue", a[m, 17] - a[m, 16]), ("ring1: final sync", a[m, 4] - a[m, 17])):
+    print(f"{name:26s} p10/p50/p90/max: {np.percentile(d,10):9.0f} {np.percentile(d,50):9.0f} {np.percentile(d,90):9.0f} {d.max():9.0f}")
+print("units per wave p50/p90/max:", np.percentile(a[m, 19], [50, 90, 100]), " max units popped by one lane p50/p90/max:", np.percentile(a[m, 18], [50, 90, 100]))
+x15 = raw[m, 15]; steps = (x15 >> np.uint64(48)).astype(int)
+drain = a[m, 17] - a[m, 16]
+A = np.vstack([np.ones_like(steps), steps]).T; coef = np.linalg.lstsq(A, drain, rcond=None)[0]
+print("drain ~ %.0f + %.0f * (max-lane window steps)" % tuple(coef), " corr", np.corrcoef(drain, steps)[0, 1])
