@@ -233,7 +233,7 @@ constexpr int kStageMaxGrow = 6;
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
 static_assert(kWalkWindow <= kSortedPad && kWalkWindow % 2 == 0, "walk windows may overhang the array by at most the sentinel frame");
 
-constexpr int kUnitCap = 288;         // queued (query, row) walks per round (ring 1 needs 32 queries x 9 rows)
+constexpr int kUnitCap = 256;         // slots of the window-task ring (a power of two)
 
 struct WaveStage {
   union {
@@ -248,10 +248,12 @@ struct WaveStage {
   // needed one row would idle.  Results meet in qkey by a 64-bit atomic min on (distance bits, position): the total order.
   unsigned long long qkey[32];  // per query: nearest so far
   float4 qtab[32];              // per query: transformed coordinates
-  // a unit: ring 1: {query | row code << 5 | (start - run start) << 9, run start, run end, (y,z) gap}; beyond: {query | listed row << 5}
+  // a window task: {query | side << 5 (0 centre, 1 right, 2 left, 3 listed row) | level << 7 | last of its level << 10 | (centre: window
+  // start - run start) << 11,  first point of the window (side 3: index of the listed row),  the run's end on the growing side (centre
+  // and right: its end; left: its start),  (y,z) gap of the row}
   int unit_q[kUnitCap], unit_s[kUnitCap], unit_e[kUnitCap];
   float unit_g[kUnitCap];
-  int q_tail, q_head;
+  int q_tail, q_cut;  // next slot to reserve; the first reservation of the current round that did not fit the ring (or INT_MAX)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -427,15 +429,17 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
     const int i = qbase + lane;
     const bool mine = lane < qcount;
     NG_STAMP(1);
-    // ---- the operands of this lane's own query (lane l <-> query qbase + l: the tail's mapping) are requested up front: their
-    //      round trips (source point -> covariance; old correspondence -> old target point) overlap everything below, and the
-    //      search takes its query and its warm start from them by shuffles instead of fetching them again ----
+    // ---- the operands of this lane's own query (lane l <-> query qbase + l: the tail's mapping), ONE round trip: the source point,
+    //      the previous correspondence with its target point, the previous Mahalanobis matrix.  K4 is evaluated at once (it needs
+    //      nothing else), so that nothing but the source point and one double stays in registers across the search; the search takes
+    //      its query and its warm start from the same loads by shuffles ----
     const bool have_prev = st->hot.have_lin != 0;
     float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
     int j_old = -1;
-    double Mold[6] = {0, 0, 0, 0, 0, 0}, ca[6] = {0, 0, 0, 0, 0, 0};
     float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    double k4 = 0.0;
     if (mine) {
+      double Mold[6] = {0, 0, 0, 0, 0, 0};
       sp = a.qpts[i];
       if (have_prev) {  // K4's correspondence and the search's warm start
         bp_old = tpt_old[i];
@@ -446,10 +450,18 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
 #pragma unroll
         for (int e = 0; e < 6; ++e) Mold[e] = M[e];
       }
-      if (do_lin) {
-        const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) ca[e] = CA[e];
+      // K4: error of the trial pose under the previous correspondences (impl/nano_gicp_impl.hpp:273-296)
+      if (do_err && j_old >= 0) {
+        const double ax = (double)sp.x, ay = (double)sp.y, az = (double)sp.z;
+        const double tax = R[0] * ax + R[1] * ay + R[2] * az + t[0];  // T * a in FP64 (impl/nano_gicp_impl.hpp:289)
+        const double tay = R[3] * ax + R[4] * ay + R[5] * az + t[1];
+        const double taz = R[6] * ax + R[7] * ay + R[8] * az + t[2];
+        const double ex = (double)bp_old.x - tax, ey = (double)bp_old.y - tay, ez = (double)bp_old.z - taz;
+        const double m00 = Mold[0], m01 = Mold[1], m02 = Mold[2], m11 = Mold[3], m12 = Mold[4], m22 = Mold[5];
+        const double mex = m00 * ex + m01 * ey + m02 * ez;
+        const double mey = m01 * ex + m11 * ey + m12 * ez;
+        const double mez = m02 * ex + m12 * ey + m22 * ez;
+        k4 = ex * mex + ey * mey + ez * mez;
       }
     }
 
@@ -558,160 +570,247 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       const bool in_box = qok && listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
       unsigned int dbg_g1 = 0, dbg_g2 = 0;
       auto pack_key = [](float d, int p) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)p; };
-      // ---- rings 0..1.  The 3 x 3 window of (y,z) rows around the query's cell; a row of it is the x-sorted run of the cells
-      //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
-      //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it).  Every
-      //      non-empty row becomes a UNIT {query, run, starting position} in an LDS queue; whichever lane is free pops the next
-      //      unit and walks it.  The walk starts at the previous correspondence when that lies in the run (the window is then
-      //      centred on the best candidate), else where qx sits inside its own cell (interpolated). ----
+      // ---- The search proper: a queue of WINDOW TASKS drained in rounds.
+      //      A (y,z) row of cells is an x-sorted run of the cell-sorted target; the nearest point of a run to the query is found by
+      //      looking at a WINDOW of kWalkWindow consecutive points where qx sits in the run and then outward, right and left, while
+      //      |dx|^2 + (y,z)-gap can still beat the best distance so far.  A lane that walks a long run alone is a chain of dependent
+      //      memory round trips that its whole wave waits for (measured: the slowest lane of a wave made ~8 such steps, the average
+      //      lane 2), so a walk is not tied to a lane: every window is a TASK in an LDS queue,
+      //          centre  the window around the starting position of a run (one per row that the gap test does not rule out);
+      //          side    a window further right / left.  A centre window queues the next window of each side that is still alive; from
+      //                  then on the LAST window of a level queues the next level - 2, then 4 windows at once (speculation: a window
+      //                  whose nearest end is already out of reach is dropped on sight, having cost one idle lane's load);
+      //          row     (beyond ring 1) a listed row of the batch region: fetch the bounds of its cells around qx, queue its centre.
+      //      Rounds: the tasks queued during one round are dealt to the 64 lanes in the next (task u -> lane u mod 64), one window =
+      //      one memory round trip per lane and round.  Results meet in a per-query 64-bit LDS atomic min on (distance bits,
+      //      position): the total order, so the outcome does not depend on which lane saw which window, nor on speculation.
+      //      The queue is a ring of kUnitCap slots; a push that would not fit is not made: the pushing lane walks that stretch
+      //      itself (scan_global_outward), exactly as every walk was done before.
       if (qok && sub == 0) {
         if (in_box) ++nstaged;
         S.qtab[grp] = make_float4(qx, qy, qz, 0.f);
         S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
       }
-      if (lane == 0) S.q_tail = 0, S.q_head = 0;
+      if (lane == 0) S.q_tail = 0, S.q_cut = 0x7fffffff;
       if (a.dbg_qstats && lane < 32) S.qstat[lane][0] = S.qstat[lane][1] = S.qstat[lane][2] = 0;
       wave_lds_sync();
-      if (qok) {
-        const float lim = fminf(best, a.gate_sq_f);
-        constexpr int kRowsPerLane = (9 + G - 1) / G;
-        struct alignas(4) Bounds4 { int v[4]; };
-        Bounds4 bnd[kRowsPerLane];
-        float gap[kRowsPerLane];
-        int code[kRowsPerLane];
-#pragma unroll
-        for (int k = 0; k < kRowsPerLane; ++k) {
-          const int order = sub + k * G;  // nearest rows first: the own row, its 4 edge neighbours, the 4 corners
-          const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
-          const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-          code[k] = -1;
-          gap[k] = 0.f;
-          if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-            gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
-            if (gap[k] <= lim) {
-              code[k] = tt;
-              bnd[k] = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + ((z * g.ny + y) * g.nx + cx - 1));  // starts of cells cx-1, cx, cx+1, cx+2
-            }
-          }
-        }
-        const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
-#pragma unroll
-        for (int k = 0; k < kRowsPerLane; ++k) {
-          if (code[k] < 0) continue;
-          const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
-          if (e0 <= s0) continue;
-          const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
-          const int slot = atomicAdd(&S.q_tail, 1);  // at most 32 x 9 units: fits
-          S.unit_q[slot] = grp | (code[k] << 5) | (min(max(m - s0, 0), (1 << 22) - 1) << 9);
-          S.unit_s[slot] = s0;
-          S.unit_e[slot] = e0;
-          S.unit_g[slot] = gap[k];
-        }
-      }
-      wave_lds_sync();
-      NG_STAMP(16);
-      {
-        const int tail = S.q_tail;
-        unsigned int popped = 0;
-        for (;;) {
-          const int u = atomicAdd(&S.q_head, 1);
-          if (u >= tail) break;
-          ++popped;
-          const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
-          const float gyz = S.unit_g[u];
-          const float4 q = S.qtab[qs];
-          const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
-          float ub = __uint_as_float((unsigned int)(k0 >> 32));
-          int up = (int)(unsigned int)k0;
-          if (gyz > fminf(ub, a.gate_sq_f)) continue;
-          const unsigned int c_before = ncand;
-          scan_global_outward(a.tgt, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
-          atomicMin(&S.qkey[qs], pack_key(ub, up));
-          if (a.dbg_qstats) {
-            atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
-            atomicAdd(&S.qstat[qs][1], 1);
-          }
-        }
-        NG_STAMP(17);
-        if (a.dbg_stamps) {
-          unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
-          atomicMax(&d[18], (unsigned long long)popped);
-          if (lane == 0) d[19] = (unsigned long long)tail;
-        }
-      }
-      wave_lds_sync();
-      if (qok) {
-        const unsigned long long k1 = S.qkey[grp];
-        best = __uint_as_float((unsigned int)(k1 >> 32));
-        pos = (int)(unsigned int)k1;
-      }
-      NG_STAMP(4);
+      constexpr int W = kWalkWindow;
+      int r_lo = 0;              // first slot of the round being drained (slots below it are free again)
+      int far_li = sub;          // beyond ring 1: next listed row this lane will look at for its query
+      bool far_more = false, need_far = false;
       float bound1 = 0.f;
-      if (qok) {
-        bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-        went_far = !(best <= bound1 || bound1 >= a.gate_sq_f);
-      }
-      const unsigned int dbg_c1 = ncand;
-      unsigned int dbg_rows = 0;
-      // ---- rings 2..grow: units for the listed rows (nearest ring first) that can still hold a closer point, in rounds of
-      //      kUnitCap; between rounds every query picks up what its units found, which prunes its remaining rows ----
-      const bool need_far = in_box && went_far;
-      if (listed && __any(need_far)) {  // wave-uniform
-        int li = sub;
-        bool more = need_far;
-        for (;;) {
-          if (lane == 0) S.q_tail = 0, S.q_head = 0;
-          wave_lds_sync();
-          if (more) {
+      unsigned int dbg_c1 = 0, dbg_rows = 0;
+      // queue `cnt` consecutive windows of one side; false (nothing queued) when the ring has no room
+      auto push_tasks = [&](int qs, int side, int lvl, int first, int step, int bound, float gap, int cnt) -> bool {
+        const int slot0 = atomicAdd(&S.q_tail, cnt);
+        if (slot0 + cnt - r_lo > kUnitCap) {  // would overwrite tasks of the round being drained: not made (every later reservation
+          atomicMin(&S.q_cut, slot0);         // fails as well; the round boundary cuts the queue at the first one)
+          return false;
+        }
+        for (int k = 0; k < cnt; ++k) {
+          const int sl = (slot0 + k) & (kUnitCap - 1);
+          S.unit_q[sl] = qs | (side << 5) | (lvl << 7) | ((k == cnt - 1 ? 1 : 0) << 10);
+          S.unit_s[sl] = first + k * step;
+          S.unit_e[sl] = bound;
+          S.unit_g[sl] = gap;
+        }
+        return true;
+      };
+      auto push_centre = [&](int qs, int s0, int e0, int m, float gap) -> bool {
+        const int w = min(max(m - W / 2, s0), max(s0, e0 - W));  // the window inside the run where the run is long enough
+        if (w - s0 >= (1 << 21)) return false;  // the run's start travels as a 21-bit offset (longer runs: the caller walks them)
+        const int slot = atomicAdd(&S.q_tail, 1);
+        if (slot + 1 - r_lo > kUnitCap) {
+          atomicMin(&S.q_cut, slot);
+          return false;
+        }
+        const int sl = slot & (kUnitCap - 1);
+        S.unit_q[sl] = qs | ((w - s0) << 11);  // side 0
+        S.unit_s[sl] = w;
+        S.unit_e[sl] = e0;
+        S.unit_g[sl] = gap;
+        return true;
+      };
+      for (int phase = 0;; ++phase) {  // phase 0: rings 0..1; phases 1, 2, ...: the listed rows beyond, kUnitCap at a time
+        if (phase == 0) {
+          // ---- rings 0..1: the 3 x 3 window of (y,z) rows around the query's cell; a row of it is the run of the cells
+          //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
+          //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it) and queues
+          //      the centre window of every non-empty row.  The walk starts at the previous correspondence when that lies in the
+          //      run (the window is then centred on the best candidate), else where qx sits inside its own cell (interpolated). ----
+          if (qok) {
             const float lim = fminf(best, a.gate_sq_f);
-            for (; li < nlive; li += G) {
-              const int4 rec = S.live[li];
-              if (row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz) > lim) continue;
-              const int slot = atomicAdd(&S.q_tail, 1);
-              if (slot >= kUnitCap) break;  // this row waits for the next round
-              S.unit_q[slot] = grp | (li << 5);
-              ++dbg_rows;
+            constexpr int kRowsPerLane = (9 + G - 1) / G;
+            struct alignas(4) Bounds4 { int v[4]; };
+            Bounds4 bnd[kRowsPerLane];
+            float gap[kRowsPerLane];
+            bool use[kRowsPerLane];
+#pragma unroll
+            for (int k = 0; k < kRowsPerLane; ++k) {
+              const int order = sub + k * G;  // nearest rows first: the own row, its 4 edge neighbours, the 4 corners
+              const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
+              const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
+              use[k] = false;
+              gap[k] = 0.f;
+              if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
+                if (gap[k] <= lim) {
+                  use[k] = true;
+                  bnd[k] = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + ((z * g.ny + y) * g.nx + cx - 1));  // starts of cells cx-1, cx, cx+1, cx+2
+                }
+              }
             }
-            more = li < nlive;
-          }
-          wave_lds_sync();
-          {
-            const int tail = min(S.q_tail, kUnitCap);
-            for (;;) {
-              const int u = atomicAdd(&S.q_head, 1);
-              if (u >= tail) break;
-              const int unit = S.unit_q[u], qs = unit & 31;
-              const int4 rec = S.live[unit >> 5];
-              const float4 q = S.qtab[qs];
-              int ux, uy, uz;
-              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
-              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, uy, uz, q.y, q.z);
-              const unsigned long long k0 = S.qkey[qs];
-              float ub = __uint_as_float((unsigned int)(k0 >> 32));
-              int up = (int)(unsigned int)k0;
-              if (gyz > fminf(ub, a.gate_sq_f)) continue;
-              // start where qx sits among the row's three centre cells (one extra round trip, but a much better start
-              // than interpolating over the whole region row: the walk is over the whole row either way)
-              const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1;
-              const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
-              const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
-              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
-              const unsigned int c_before = ncand;
-              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
-              atomicMin(&S.qkey[qs], pack_key(ub, up));
-              if (a.dbg_qstats) {
-                atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
-                atomicAdd(&S.qstat[qs][1], 1 << 16);
+            const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
+#pragma unroll
+            for (int k = 0; k < kRowsPerLane; ++k) {
+              if (!use[k]) continue;
+              const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
+              if (e0 <= s0) continue;
+              const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
+              if (!push_centre(grp, s0, e0, m, gap[k])) {  // no room (only when nearly every query of a batch has all nine rows): walk it here
+                float ub = best;
+                int up = pos;
+                scan_global_outward(a.tgt, s0, e0, m, qx, qy, qz, gap[k], a.gate_sq_f, ub, up, ncand, dbg_g1);
+                atomicMin(&S.qkey[grp], pack_key(ub, up));
               }
             }
           }
-          wave_lds_sync();
-          if (in_box) {
-            const unsigned long long k1 = S.qkey[grp];
-            best = __uint_as_float((unsigned int)(k1 >> 32));
-            pos = (int)(unsigned int)k1;
+          NG_STAMP(16);
+        } else {
+          // ---- beyond ring 1: the listed rows (nearest ring first) that can still hold a closer point ----
+          if (phase == 1) {
+            NG_STAMP(4);
+            if (qok) {
+              bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
+              went_far = !(best <= bound1 || bound1 >= a.gate_sq_f);
+            }
+            dbg_c1 = ncand;
+            need_far = in_box && went_far;
+            far_more = need_far;
+            if (!(listed && __any(need_far))) break;  // wave-uniform
+          } else if (!__any(far_more)) {
+            break;
           }
-          if (!__any(more)) break;
+          if (lane == 0) S.q_tail = 0, S.q_cut = 0x7fffffff;
+          r_lo = 0;
+          wave_lds_sync();
+          if (far_more) {
+            const float lim = fminf(best, a.gate_sq_f);
+            for (; far_li < nlive; far_li += G) {
+              const int4 rec = S.live[far_li];
+              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz);
+              if (gyz > lim) continue;
+              if (!push_tasks(grp, 3, 0, far_li, 0, 0, gyz, 1)) break;  // this row waits for the next phase
+              ++dbg_rows;
+            }
+            far_more = far_li < nlive;
+          }
+        }
+        // ---- drain the queue, round by round ----
+        for (;;) {
+          wave_lds_sync();  // the tasks queued by the enqueue phase / the previous round are visible
+          const int r_hi = min(__builtin_amdgcn_readfirstlane(S.q_tail), __builtin_amdgcn_readfirstlane(S.q_cut));
+          if (r_lo >= r_hi) break;
+          wave_lds_sync();  // everyone has read the two words
+          if (lane == 0) S.q_tail = r_hi, S.q_cut = 0x7fffffff;  // reservations that did not fit are taken back
+          wave_lds_sync();
+          for (int u = r_lo + lane; u < r_hi; u += 64) {
+            const int sl = u & (kUnitCap - 1);
+            const int uq = S.unit_q[sl], ua = S.unit_s[sl], ubnd = S.unit_e[sl];
+            const float gyz = S.unit_g[sl];
+            const int qs = uq & 31, side = (uq >> 5) & 3;
+            const float4 q = S.qtab[qs];
+            const unsigned long long k0 = S.qkey[qs];  // whatever the query's other windows have found by now
+            float ub = __uint_as_float((unsigned int)(k0 >> 32));
+            int up = (int)(unsigned int)k0;
+            const float lim0 = fminf(ub, a.gate_sq_f);
+            if (gyz > lim0) continue;
+            bool fb = false;  // no room in the ring for what this task wanted to queue: the stretch [fs, fe) is walked here, from fm
+            int fs = 0, fe = 0, fm = 0;
+            if (side == 3) {  // a listed row: where does qx sit in it?  (one round trip; its centre window goes into the next round)
+              const int4 rec = S.live[ua];
+              int ux, uy, uz;
+              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
+              struct alignas(4) Bounds4 { int v[4]; };
+              const Bounds4 bq = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + (((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx + ux - 1));
+              const float fxq = fminf(fmaxf((q.x - (g.ox + (float)ux * g.h)) * g.inv_h, 0.f), 1.f);
+              const int s0 = rec.z, e0 = rec.z + rec.y;
+              const int m = (up >= s0 && up < e0) ? up : min(max(bq.v[1] + (int)(fxq * (float)(bq.v[2] - bq.v[1])), s0), e0 - 1);
+              if (a.dbg_qstats) atomicAdd(&S.qstat[qs][1], 1 << 16);
+              if (!push_centre(qs, s0, e0, m, gyz)) fb = true, fs = s0, fe = e0, fm = m;
+            } else {
+            // one window [ua, ua + W): always read in increasing position, so that c[0] / c[W-1] are its smallest / largest x and,
+            // among equal distances, the first one met has the smallest position (strict `<` below).  No index clamps: a window
+            // that overhangs its run reads points of the neighbouring runs (genuine target points: they can only be legitimate
+            // candidates) or the sentinels that frame the array (infinitely far).
+            const float4* __restrict__ wp = a.tgt + ua;
+            float4 c[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) c[j] = wp[j];
+            const float dr = c[W - 1].x - q.x, dl = q.x - c[0].x;
+            // a speculative side window whose nearest end is already out of reach: dropped on sight
+            if (side == 1 && -dl > 0.f && dl * dl + gyz > lim0) continue;
+            if (side == 2 && -dr > 0.f && dr * dr + gyz > lim0) continue;
+            float lb = sqdist(q.x, q.y, q.z, c[0]);
+            int lj = 0;
+#pragma unroll
+            for (int j = 1; j < W; ++j) {
+              const float d = sqdist(q.x, q.y, q.z, c[j]);
+              if (d < lb) { lb = d; lj = j; }
+            }
+            if (nn_better(lb, ua + lj, ub, up)) {
+              ub = lb;
+              up = ua + lj;
+              atomicMin(&S.qkey[qs], pack_key(ub, up));
+            }
+            ncand += W;
+            if (phase == 0) ++dbg_g1; else ++dbg_g2;
+            if (a.dbg_qstats) {
+              atomicAdd(&S.qstat[qs][phase == 0 ? 0 : 2], W);
+              if (side == 0 && phase == 0) atomicAdd(&S.qstat[qs][1], 1);
+            }
+            // what to queue next
+            const float lim = fminf(ub, a.gate_sq_f);
+            const int lvl = (uq >> 7) & 7;
+            if (side == 0) {
+              const int s0 = ua - (uq >> 11), e0 = ubnd, hi = ua + W, lo = ua;
+              if (hi < e0 && !(dr > 0.f && dr * dr + gyz > lim)) {
+                if (!push_tasks(qs, 1, 1, hi, W, e0, gyz, 1)) fb = true, fs = hi, fe = e0, fm = hi;
+              }
+              if (lo > s0 && !(dl > 0.f && dl * dl + gyz > lim)) {
+                if (fb) fs = s0, fm = ua;  // both sides at once: the whole run again (the centre window is rescanned: harmless)
+                else if (!push_tasks(qs, 2, 1, lo - W, -W, s0, gyz, 1)) fb = true, fs = s0, fe = lo, fm = lo - 1;
+              }
+            } else if ((uq >> 10) & 1) {  // the last window of its level queues the next level
+              const int cnt_max = lvl >= 2 ? 4 : 2;
+              if (side == 1) {
+                const int e0 = ubnd, hi = ua + W;
+                if (hi < e0 && !(dr > 0.f && dr * dr + gyz > lim)) {
+                  const int cnt = min(cnt_max, (e0 - hi + W - 1) / W);
+                  if (!push_tasks(qs, 1, min(lvl + 1, 7), hi, W, e0, gyz, cnt)) fb = true, fs = hi, fe = e0, fm = hi;
+                }
+              } else {
+                const int s0 = ubnd, lo = ua;
+                if (lo > s0 && !(dl > 0.f && dl * dl + gyz > lim)) {
+                  const int cnt = min(cnt_max, (lo - s0 + W - 1) / W);
+                  if (!push_tasks(qs, 2, min(lvl + 1, 7), lo - W, -W, s0, gyz, cnt)) fb = true, fs = s0, fe = lo, fm = lo - 1;
+                }
+              }
+            }
+            }
+            if (fb) {
+              scan_global_outward(a.tgt, fs, fe, fm, q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              atomicMin(&S.qkey[qs], pack_key(ub, up));
+            }
+          }
+          r_lo = r_hi;
+        }
+        NG_STAMP(17);
+        wave_lds_sync();
+        if (qok) {  // every query picks up what its windows found (which prunes its remaining rows in the next phase)
+          const unsigned long long k1 = S.qkey[grp];
+          best = __uint_as_float((unsigned int)(k1 >> 32));
+          pos = (int)(unsigned int)k1;
         }
       }
       NG_STAMP(5);
@@ -751,15 +850,7 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
       const double tay = R[3] * ax + R[4] * ay + R[5] * az + t[1];
       const double taz = R[6] * ax + R[7] * ay + R[8] * az + t[2];
 
-      // K4: error of the trial pose under the previous correspondences (impl/nano_gicp_impl.hpp:273-296)
-      if (do_err && j_old >= 0) {
-        const double ex = (double)bp_old.x - tax, ey = (double)bp_old.y - tay, ez = (double)bp_old.z - taz;
-        const double m00 = Mold[0], m01 = Mold[1], m02 = Mold[2], m11 = Mold[3], m12 = Mold[4], m22 = Mold[5];
-        const double mex = m00 * ex + m01 * ey + m02 * ez;
-        const double mey = m01 * ex + m11 * ey + m12 * ez;
-        const double mez = m02 * ex + m12 * ey + m22 * ez;
-        acc[28] += ex * mex + ey * mey + ez * mez;
-      }
+      acc[28] += k4;  // K4, evaluated before the search
       if (do_lin) {
         const int pos = mypos;
         const bool valid = (pos >= 0) && ((double)mybest < a.gate_sq);  // impl/nano_gicp_impl.hpp:195
@@ -768,7 +859,11 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
           ++nvalid;
           // Mahalanobis: (C_B + R C_A R^T)^-1  (impl/nano_gicp_impl.hpp:205-209)
           const double* CB = a.cov_tgt + (size_t)pos * 6;
+          const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;  // same round trip as the target's
           const float4 bp = a.tgt[pos];
+          double ca[6];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) ca[e] = CA[e];
           tpt_new[i] = make_float4(bp.x, bp.y, bp.z, __int_as_float(pos));
           double rcr[6], M[6];
           rotate_sym(R, ca, rcr);
