@@ -234,6 +234,10 @@ constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one m
 static_assert(kWalkWindow <= kSortedPad && kWalkWindow % 2 == 0, "walk windows may overhang the array by at most the sentinel frame");
 
 constexpr int kUnitCap = 256;         // slots of the window-task ring (a power of two)
+#ifndef NGICP_WALK_BUDGET
+#define NGICP_WALK_BUDGET 3
+#endif
+constexpr int kWalkBudget = NGICP_WALK_BUDGET;  // windows a task walks on one side beyond its first before it queues the rest
 
 struct WaveStage {
   union {
@@ -381,7 +385,7 @@ constexpr int kStampStride = 24;
   } while (0)
 
 template <int G>
-__global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
+__global__ void __launch_bounds__(256, 3) k_gicp_pass(PassArgs a) {
   constexpr int B = 64 / G;  // queries per wave batch
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
@@ -739,62 +743,88 @@ __global__ void __launch_bounds__(256) k_gicp_pass(PassArgs a) {
               if (a.dbg_qstats) atomicAdd(&S.qstat[qs][1], 1 << 16);
               if (!push_centre(qs, s0, e0, m, gyz)) fb = true, fs = s0, fe = e0, fm = m;
             } else {
-            // one window [ua, ua + W): always read in increasing position, so that c[0] / c[W-1] are its smallest / largest x and,
-            // among equal distances, the first one met has the smallest position (strict `<` below).  No index clamps: a window
-            // that overhangs its run reads points of the neighbouring runs (genuine target points: they can only be legitimate
-            // candidates) or the sentinels that frame the array (infinitely far).
-            const float4* __restrict__ wp = a.tgt + ua;
-            float4 c[W];
+            // A walker: windows of W points, one memory round trip each, outward from the task's first window: a centre task goes
+            // right, then left; a side task goes its own way.  At most kWalkBudget windows per side and task: what is still alive
+            // then is queued for the next round (2, later 4 tasks of kWalkBudget windows each - speculation; only the LAST task of
+            // a level queues the next level, the others end where their neighbour begins).  Most walks (<= 1 + 2 x budget windows)
+            // end inside their centre task, exactly as the serial walk did; the long ones spread over the idle lanes.
+            // A window is read in increasing position, so that c[0] / c[W-1] are its smallest / largest x and, among equal
+            // distances, the first one met has the smallest position (strict `<` below).  No index clamps: a window that overhangs
+            // its run reads points of the neighbouring runs (genuine target points: they can only be legitimate candidates) or the
+            // sentinels that frame the array (infinitely far).
+            const int lvl = (uq >> 7) & 7;
+            const bool may_queue = side == 0 || ((uq >> 10) & 1);
+            const int s_run = side == 0 ? ua - (uq >> 11) : (side == 2 ? ubnd : 0x7fffffff);  // a right task never looks left,
+            const int e_run = side == 2 ? -1 : ubnd;                                          // a left task never right
+            int w = ua, lo = ua, hi = ua + W, dir = side == 0 ? 0 : (side == 1 ? 1 : -1);
+            int steps_r = 0, steps_l = 0, rem_hi = -1, rem_lo = -1;
+            bool go_left = false, improved = false;
+            for (bool first = true;; first = false) {
+              const float4* __restrict__ wp = a.tgt + w;
+              float4 c[W];
 #pragma unroll
-            for (int j = 0; j < W; ++j) c[j] = wp[j];
-            const float dr = c[W - 1].x - q.x, dl = q.x - c[0].x;
-            // a speculative side window whose nearest end is already out of reach: dropped on sight
-            if (side == 1 && -dl > 0.f && dl * dl + gyz > lim0) continue;
-            if (side == 2 && -dr > 0.f && dr * dr + gyz > lim0) continue;
-            float lb = sqdist(q.x, q.y, q.z, c[0]);
-            int lj = 0;
+              for (int j = 0; j < W; ++j) c[j] = wp[j];
+              const float dr = c[W - 1].x - q.x, dl = q.x - c[0].x;
+              if (first && side != 0) {  // a speculative task whose nearest end is already out of reach: dropped on sight
+                const float dn = side == 1 ? -dl : -dr;
+                if (dn > 0.f && dn * dn + gyz > lim0) break;
+              }
+              float lb = sqdist(q.x, q.y, q.z, c[0]);
+              int lj = 0;
 #pragma unroll
-            for (int j = 1; j < W; ++j) {
-              const float d = sqdist(q.x, q.y, q.z, c[j]);
-              if (d < lb) { lb = d; lj = j; }
+              for (int j = 1; j < W; ++j) {
+                const float d = sqdist(q.x, q.y, q.z, c[j]);
+                if (d < lb) { lb = d; lj = j; }
+              }
+              if (nn_better(lb, w + lj, ub, up)) {
+                ub = lb;
+                up = w + lj;
+                improved = true;
+              }
+              ncand += W;
+              if (phase == 0) ++dbg_g1; else ++dbg_g2;
+              const float lim = fminf(ub, a.gate_sq_f);
+              const bool more_right = hi < e_run && !(dr > 0.f && dr * dr + gyz > lim);
+              const bool more_left = lo > s_run && !(dl > 0.f && dl * dl + gyz > lim);
+              if (dir == 0) go_left = more_left;
+              if (dir >= 0 && more_right) {
+                if (steps_r < kWalkBudget) {
+                  dir = 1;
+                  w = hi;
+                  hi += W;
+                  ++steps_r;
+                  continue;
+                }
+                rem_hi = hi;  // alive beyond the budget: queued below
+              }
+              if (dir >= 0 ? go_left : more_left) {
+                if (steps_l < kWalkBudget) {
+                  dir = -1;
+                  lo -= W;
+                  w = lo;
+                  ++steps_l;
+                  continue;
+                }
+                rem_lo = lo;
+              }
+              break;
             }
-            if (nn_better(lb, ua + lj, ub, up)) {
-              ub = lb;
-              up = ua + lj;
-              atomicMin(&S.qkey[qs], pack_key(ub, up));
-            }
-            ncand += W;
-            if (phase == 0) ++dbg_g1; else ++dbg_g2;
+            if (improved) atomicMin(&S.qkey[qs], pack_key(ub, up));
             if (a.dbg_qstats) {
-              atomicAdd(&S.qstat[qs][phase == 0 ? 0 : 2], W);
+              atomicAdd(&S.qstat[qs][phase == 0 ? 0 : 2], (1 + steps_r + steps_l) * W);
               if (side == 0 && phase == 0) atomicAdd(&S.qstat[qs][1], 1);
             }
-            // what to queue next
-            const float lim = fminf(ub, a.gate_sq_f);
-            const int lvl = (uq >> 7) & 7;
-            if (side == 0) {
-              const int s0 = ua - (uq >> 11), e0 = ubnd, hi = ua + W, lo = ua;
-              if (hi < e0 && !(dr > 0.f && dr * dr + gyz > lim)) {
-                if (!push_tasks(qs, 1, 1, hi, W, e0, gyz, 1)) fb = true, fs = hi, fe = e0, fm = hi;
+            if (may_queue) {
+              constexpr int kChunk = (1 + kWalkBudget) * W;  // points a side task covers
+              const int cnt_max = lvl >= 1 ? 4 : 2;
+              if (rem_hi >= 0) {
+                const int cnt = min(cnt_max, (e_run - rem_hi + kChunk - 1) / kChunk);
+                if (!push_tasks(qs, 1, min(lvl + 1, 7), rem_hi, kChunk, e_run, gyz, cnt)) fb = true, fs = rem_hi, fe = e_run, fm = rem_hi;
               }
-              if (lo > s0 && !(dl > 0.f && dl * dl + gyz > lim)) {
-                if (fb) fs = s0, fm = ua;  // both sides at once: the whole run again (the centre window is rescanned: harmless)
-                else if (!push_tasks(qs, 2, 1, lo - W, -W, s0, gyz, 1)) fb = true, fs = s0, fe = lo, fm = lo - 1;
-              }
-            } else if ((uq >> 10) & 1) {  // the last window of its level queues the next level
-              const int cnt_max = lvl >= 2 ? 4 : 2;
-              if (side == 1) {
-                const int e0 = ubnd, hi = ua + W;
-                if (hi < e0 && !(dr > 0.f && dr * dr + gyz > lim)) {
-                  const int cnt = min(cnt_max, (e0 - hi + W - 1) / W);
-                  if (!push_tasks(qs, 1, min(lvl + 1, 7), hi, W, e0, gyz, cnt)) fb = true, fs = hi, fe = e0, fm = hi;
-                }
-              } else {
-                const int s0 = ubnd, lo = ua;
-                if (lo > s0 && !(dl > 0.f && dl * dl + gyz > lim)) {
-                  const int cnt = min(cnt_max, (lo - s0 + W - 1) / W);
-                  if (!push_tasks(qs, 2, min(lvl + 1, 7), lo - W, -W, s0, gyz, cnt)) fb = true, fs = s0, fe = lo, fm = lo - 1;
-                }
+              if (rem_lo >= 0) {
+                const int cnt = min(cnt_max, (rem_lo - s_run + kChunk - 1) / kChunk);
+                if (fb) fs = s_run, fm = min(rem_lo, fe - 1);  // both sides: one walk over the whole run (part of it rescanned: harmless)
+                else if (!push_tasks(qs, 2, min(lvl + 1, 7), rem_lo - W, -kChunk, s_run, gyz, cnt)) fb = true, fs = s_run, fe = rem_lo, fm = rem_lo - 1;
               }
             }
             }
