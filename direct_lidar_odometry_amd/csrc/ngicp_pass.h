@@ -227,17 +227,16 @@ constexpr int kStageRows = 64 * kStageRowsPerLane;  // (y,z) rows of a batch reg
 constexpr int kStageXs = 20;         // cells per row of the region
 constexpr int kStageMaxGrow = 6;
 
+#ifndef NGICP_PASS_WAVES
+#define NGICP_PASS_WAVES 4  // waves per SIMD the pass kernel is compiled for (4: <= 128 VGPRs, four blocks of 40 KB LDS per CU)
+#endif
 #ifndef NGICP_WALK_WINDOW
 #define NGICP_WALK_WINDOW 12
 #endif
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
 static_assert(kWalkWindow <= kSortedPad && kWalkWindow % 2 == 0, "walk windows may overhang the array by at most the sentinel frame");
 
-constexpr int kUnitCap = 256;         // slots of the window-task ring (a power of two)
-#ifndef NGICP_WALK_BUDGET
-#define NGICP_WALK_BUDGET 3
-#endif
-constexpr int kWalkBudget = NGICP_WALK_BUDGET;  // windows a task walks on one side beyond its first before it queues the rest
+constexpr int kUnitCap = 288;         // queued (query, row) walks per round (ring 1 needs 32 queries x 9 rows)
 
 struct WaveStage {
   union {
@@ -245,19 +244,17 @@ struct WaveStage {
       int4 live[kStageRows];  // one record per NON-EMPTY row of the region, nearest ring first: {y | z << 16, points, first point, -}
       int qstat[32][3];       // diagnostic counters (PassArgs::dbg_qstats)
     };
-    double red[32 * 30];  // the per-batch reduction reuses the (then idle) tables as scratch
+    double red[16 * 30];  // the per-batch reduction reuses the (then idle) tables as scratch, sixteen queries at a time
   };
   // Work distribution inside the wave: a (query, row) walk is a UNIT.  Units are queued here and popped by whichever lane is
   // free, so a query that needs twenty rows is served by twenty lanes instead of its own two while the lanes of queries that
   // needed one row would idle.  Results meet in qkey by a 64-bit atomic min on (distance bits, position): the total order.
   unsigned long long qkey[32];  // per query: nearest so far
   float4 qtab[32];              // per query: transformed coordinates
-  // a window task: {query | side << 5 (0 centre, 1 right, 2 left, 3 listed row) | level << 7 | last of its level << 10 | (centre: window
-  // start - run start) << 11,  first point of the window (side 3: index of the listed row),  the run's end on the growing side (centre
-  // and right: its end; left: its start),  (y,z) gap of the row}
+  // a unit: ring 1: {query | row code << 5 | (start - run start) << 9, run start, run end, (y,z) gap}; beyond: {query | listed row << 5}
   int unit_q[kUnitCap], unit_s[kUnitCap], unit_e[kUnitCap];
   float unit_g[kUnitCap];
-  int q_tail, q_cut;  // next slot to reserve; the first reservation of the current round that did not fit the ring (or INT_MAX)
+  int q_tail, q_head;
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -385,7 +382,7 @@ constexpr int kStampStride = 24;
   } while (0)
 
 template <int G>
-__global__ void __launch_bounds__(256, 3) k_gicp_pass(PassArgs a) {
+__global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a) {
   constexpr int B = 64 / G;  // queries per wave batch
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
@@ -574,273 +571,160 @@ __global__ void __launch_bounds__(256, 3) k_gicp_pass(PassArgs a) {
       const bool in_box = qok && listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
       unsigned int dbg_g1 = 0, dbg_g2 = 0;
       auto pack_key = [](float d, int p) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)p; };
-      // ---- The search proper: a queue of WINDOW TASKS drained in rounds.
-      //      A (y,z) row of cells is an x-sorted run of the cell-sorted target; the nearest point of a run to the query is found by
-      //      looking at a WINDOW of kWalkWindow consecutive points where qx sits in the run and then outward, right and left, while
-      //      |dx|^2 + (y,z)-gap can still beat the best distance so far.  A lane that walks a long run alone is a chain of dependent
-      //      memory round trips that its whole wave waits for (measured: the slowest lane of a wave made ~8 such steps, the average
-      //      lane 2), so a walk is not tied to a lane: every window is a TASK in an LDS queue,
-      //          centre  the window around the starting position of a run (one per row that the gap test does not rule out);
-      //          side    a window further right / left.  A centre window queues the next window of each side that is still alive; from
-      //                  then on the LAST window of a level queues the next level - 2, then 4 windows at once (speculation: a window
-      //                  whose nearest end is already out of reach is dropped on sight, having cost one idle lane's load);
-      //          row     (beyond ring 1) a listed row of the batch region: fetch the bounds of its cells around qx, queue its centre.
-      //      Rounds: the tasks queued during one round are dealt to the 64 lanes in the next (task u -> lane u mod 64), one window =
-      //      one memory round trip per lane and round.  Results meet in a per-query 64-bit LDS atomic min on (distance bits,
-      //      position): the total order, so the outcome does not depend on which lane saw which window, nor on speculation.
-      //      The queue is a ring of kUnitCap slots; a push that would not fit is not made: the pushing lane walks that stretch
-      //      itself (scan_global_outward), exactly as every walk was done before.
+      // ---- rings 0..1.  The 3 x 3 window of (y,z) rows around the query's cell; a row of it is the x-sorted run of the cells
+      //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
+      //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it).  Every
+      //      non-empty row becomes a UNIT {query, run, starting position} in an LDS queue; whichever lane is free pops the next
+      //      unit and walks it.  The walk starts at the previous correspondence when that lies in the run (the window is then
+      //      centred on the best candidate), else where qx sits inside its own cell (interpolated). ----
       if (qok && sub == 0) {
         if (in_box) ++nstaged;
         S.qtab[grp] = make_float4(qx, qy, qz, 0.f);
         S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
       }
-      if (lane == 0) S.q_tail = 0, S.q_cut = 0x7fffffff;
+      if (lane == 0) S.q_tail = 0, S.q_head = 0;
       if (a.dbg_qstats && lane < 32) S.qstat[lane][0] = S.qstat[lane][1] = S.qstat[lane][2] = 0;
       wave_lds_sync();
-      constexpr int W = kWalkWindow;
-      int r_lo = 0;              // first slot of the round being drained (slots below it are free again)
-      int far_li = sub;          // beyond ring 1: next listed row this lane will look at for its query
-      bool far_more = false, need_far = false;
-      float bound1 = 0.f;
-      unsigned int dbg_c1 = 0, dbg_rows = 0;
-      // queue `cnt` consecutive windows of one side; false (nothing queued) when the ring has no room
-      auto push_tasks = [&](int qs, int side, int lvl, int first, int step, int bound, float gap, int cnt) -> bool {
-        const int slot0 = atomicAdd(&S.q_tail, cnt);
-        if (slot0 + cnt - r_lo > kUnitCap) {  // would overwrite tasks of the round being drained: not made (every later reservation
-          atomicMin(&S.q_cut, slot0);         // fails as well; the round boundary cuts the queue at the first one)
-          return false;
-        }
-        for (int k = 0; k < cnt; ++k) {
-          const int sl = (slot0 + k) & (kUnitCap - 1);
-          S.unit_q[sl] = qs | (side << 5) | (lvl << 7) | ((k == cnt - 1 ? 1 : 0) << 10);
-          S.unit_s[sl] = first + k * step;
-          S.unit_e[sl] = bound;
-          S.unit_g[sl] = gap;
-        }
-        return true;
-      };
-      auto push_centre = [&](int qs, int s0, int e0, int m, float gap) -> bool {
-        const int w = min(max(m - W / 2, s0), max(s0, e0 - W));  // the window inside the run where the run is long enough
-        if (w - s0 >= (1 << 21)) return false;  // the run's start travels as a 21-bit offset (longer runs: the caller walks them)
-        const int slot = atomicAdd(&S.q_tail, 1);
-        if (slot + 1 - r_lo > kUnitCap) {
-          atomicMin(&S.q_cut, slot);
-          return false;
-        }
-        const int sl = slot & (kUnitCap - 1);
-        S.unit_q[sl] = qs | ((w - s0) << 11);  // side 0
-        S.unit_s[sl] = w;
-        S.unit_e[sl] = e0;
-        S.unit_g[sl] = gap;
-        return true;
-      };
-      for (int phase = 0;; ++phase) {  // phase 0: rings 0..1; phases 1, 2, ...: the listed rows beyond, kUnitCap at a time
-        if (phase == 0) {
-          // ---- rings 0..1: the 3 x 3 window of (y,z) rows around the query's cell; a row of it is the run of the cells
-          //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
-          //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it) and queues
-          //      the centre window of every non-empty row.  The walk starts at the previous correspondence when that lies in the
-          //      run (the window is then centred on the best candidate), else where qx sits inside its own cell (interpolated). ----
-          if (qok) {
-            const float lim = fminf(best, a.gate_sq_f);
-            constexpr int kRowsPerLane = (9 + G - 1) / G;
-            struct alignas(4) Bounds4 { int v[4]; };
-            Bounds4 bnd[kRowsPerLane];
-            float gap[kRowsPerLane];
-            bool use[kRowsPerLane];
+      if (qok) {
+        const float lim = fminf(best, a.gate_sq_f);
+        constexpr int kRowsPerLane = (9 + G - 1) / G;
+        struct alignas(4) Bounds4 { int v[4]; };
+        Bounds4 bnd[kRowsPerLane];
+        float gap[kRowsPerLane];
+        int code[kRowsPerLane];
 #pragma unroll
-            for (int k = 0; k < kRowsPerLane; ++k) {
-              const int order = sub + k * G;  // nearest rows first: the own row, its 4 edge neighbours, the 4 corners
-              const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
-              const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-              use[k] = false;
-              gap[k] = 0.f;
-              if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-                gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
-                if (gap[k] <= lim) {
-                  use[k] = true;
-                  bnd[k] = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + ((z * g.ny + y) * g.nx + cx - 1));  // starts of cells cx-1, cx, cx+1, cx+2
-                }
-              }
+        for (int k = 0; k < kRowsPerLane; ++k) {
+          const int order = sub + k * G;  // nearest rows first: the own row, its 4 edge neighbours, the 4 corners
+          const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
+          const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
+          code[k] = -1;
+          gap[k] = 0.f;
+          if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
+            if (gap[k] <= lim) {
+              code[k] = tt;
+              bnd[k] = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + ((z * g.ny + y) * g.nx + cx - 1));  // starts of cells cx-1, cx, cx+1, cx+2
             }
-            const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
-#pragma unroll
-            for (int k = 0; k < kRowsPerLane; ++k) {
-              if (!use[k]) continue;
-              const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
-              if (e0 <= s0) continue;
-              const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
-              if (!push_centre(grp, s0, e0, m, gap[k])) {  // no room (only when nearly every query of a batch has all nine rows): walk it here
-                float ub = best;
-                int up = pos;
-                scan_global_outward(a.tgt, s0, e0, m, qx, qy, qz, gap[k], a.gate_sq_f, ub, up, ncand, dbg_g1);
-                atomicMin(&S.qkey[grp], pack_key(ub, up));
-              }
-            }
-          }
-          NG_STAMP(16);
-        } else {
-          // ---- beyond ring 1: the listed rows (nearest ring first) that can still hold a closer point ----
-          if (phase == 1) {
-            NG_STAMP(4);
-            if (qok) {
-              bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-              went_far = !(best <= bound1 || bound1 >= a.gate_sq_f);
-            }
-            dbg_c1 = ncand;
-            need_far = in_box && went_far;
-            far_more = need_far;
-            if (!(listed && __any(need_far))) break;  // wave-uniform
-          } else if (!__any(far_more)) {
-            break;
-          }
-          if (lane == 0) S.q_tail = 0, S.q_cut = 0x7fffffff;
-          r_lo = 0;
-          wave_lds_sync();
-          if (far_more) {
-            const float lim = fminf(best, a.gate_sq_f);
-            for (; far_li < nlive; far_li += G) {
-              const int4 rec = S.live[far_li];
-              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz);
-              if (gyz > lim) continue;
-              if (!push_tasks(grp, 3, 0, far_li, 0, 0, gyz, 1)) break;  // this row waits for the next phase
-              ++dbg_rows;
-            }
-            far_more = far_li < nlive;
           }
         }
-        // ---- drain the queue, round by round ----
+        const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
+#pragma unroll
+        for (int k = 0; k < kRowsPerLane; ++k) {
+          if (code[k] < 0) continue;
+          const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
+          if (e0 <= s0) continue;
+          const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
+          const int slot = atomicAdd(&S.q_tail, 1);  // at most 32 x 9 units: fits
+          S.unit_q[slot] = grp | (code[k] << 5) | (min(max(m - s0, 0), (1 << 22) - 1) << 9);
+          S.unit_s[slot] = s0;
+          S.unit_e[slot] = e0;
+          S.unit_g[slot] = gap[k];
+        }
+      }
+      wave_lds_sync();
+      NG_STAMP(16);
+      {
+        const int tail = S.q_tail;
+        unsigned int popped = 0;
         for (;;) {
-          wave_lds_sync();  // the tasks queued by the enqueue phase / the previous round are visible
-          const int r_hi = min(__builtin_amdgcn_readfirstlane(S.q_tail), __builtin_amdgcn_readfirstlane(S.q_cut));
-          if (r_lo >= r_hi) break;
-          wave_lds_sync();  // everyone has read the two words
-          if (lane == 0) S.q_tail = r_hi, S.q_cut = 0x7fffffff;  // reservations that did not fit are taken back
-          wave_lds_sync();
-          for (int u = r_lo + lane; u < r_hi; u += 64) {
-            const int sl = u & (kUnitCap - 1);
-            const int uq = S.unit_q[sl], ua = S.unit_s[sl], ubnd = S.unit_e[sl];
-            const float gyz = S.unit_g[sl];
-            const int qs = uq & 31, side = (uq >> 5) & 3;
-            const float4 q = S.qtab[qs];
-            const unsigned long long k0 = S.qkey[qs];  // whatever the query's other windows have found by now
-            float ub = __uint_as_float((unsigned int)(k0 >> 32));
-            int up = (int)(unsigned int)k0;
-            const float lim0 = fminf(ub, a.gate_sq_f);
-            if (gyz > lim0) continue;
-            bool fb = false;  // no room in the ring for what this task wanted to queue: the stretch [fs, fe) is walked here, from fm
-            int fs = 0, fe = 0, fm = 0;
-            if (side == 3) {  // a listed row: where does qx sit in it?  (one round trip; its centre window goes into the next round)
-              const int4 rec = S.live[ua];
-              int ux, uy, uz;
-              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
-              struct alignas(4) Bounds4 { int v[4]; };
-              const Bounds4 bq = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + (((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx + ux - 1));
-              const float fxq = fminf(fmaxf((q.x - (g.ox + (float)ux * g.h)) * g.inv_h, 0.f), 1.f);
-              const int s0 = rec.z, e0 = rec.z + rec.y;
-              const int m = (up >= s0 && up < e0) ? up : min(max(bq.v[1] + (int)(fxq * (float)(bq.v[2] - bq.v[1])), s0), e0 - 1);
-              if (a.dbg_qstats) atomicAdd(&S.qstat[qs][1], 1 << 16);
-              if (!push_centre(qs, s0, e0, m, gyz)) fb = true, fs = s0, fe = e0, fm = m;
-            } else {
-            // A walker: windows of W points, one memory round trip each, outward from the task's first window: a centre task goes
-            // right, then left; a side task goes its own way.  At most kWalkBudget windows per side and task: what is still alive
-            // then is queued for the next round (2, later 4 tasks of kWalkBudget windows each - speculation; only the LAST task of
-            // a level queues the next level, the others end where their neighbour begins).  Most walks (<= 1 + 2 x budget windows)
-            // end inside their centre task, exactly as the serial walk did; the long ones spread over the idle lanes.
-            // A window is read in increasing position, so that c[0] / c[W-1] are its smallest / largest x and, among equal
-            // distances, the first one met has the smallest position (strict `<` below).  No index clamps: a window that overhangs
-            // its run reads points of the neighbouring runs (genuine target points: they can only be legitimate candidates) or the
-            // sentinels that frame the array (infinitely far).
-            const int lvl = (uq >> 7) & 7;
-            const bool may_queue = side == 0 || ((uq >> 10) & 1);
-            const int s_run = side == 0 ? ua - (uq >> 11) : (side == 2 ? ubnd : 0x7fffffff);  // a right task never looks left,
-            const int e_run = side == 2 ? -1 : ubnd;                                          // a left task never right
-            int w = ua, lo = ua, hi = ua + W, dir = side == 0 ? 0 : (side == 1 ? 1 : -1);
-            int steps_r = 0, steps_l = 0, rem_hi = -1, rem_lo = -1;
-            bool go_left = false, improved = false;
-            for (bool first = true;; first = false) {
-              const float4* __restrict__ wp = a.tgt + w;
-              float4 c[W];
-#pragma unroll
-              for (int j = 0; j < W; ++j) c[j] = wp[j];
-              const float dr = c[W - 1].x - q.x, dl = q.x - c[0].x;
-              if (first && side != 0) {  // a speculative task whose nearest end is already out of reach: dropped on sight
-                const float dn = side == 1 ? -dl : -dr;
-                if (dn > 0.f && dn * dn + gyz > lim0) break;
-              }
-              float lb = sqdist(q.x, q.y, q.z, c[0]);
-              int lj = 0;
-#pragma unroll
-              for (int j = 1; j < W; ++j) {
-                const float d = sqdist(q.x, q.y, q.z, c[j]);
-                if (d < lb) { lb = d; lj = j; }
-              }
-              if (nn_better(lb, w + lj, ub, up)) {
-                ub = lb;
-                up = w + lj;
-                improved = true;
-              }
-              ncand += W;
-              if (phase == 0) ++dbg_g1; else ++dbg_g2;
-              const float lim = fminf(ub, a.gate_sq_f);
-              const bool more_right = hi < e_run && !(dr > 0.f && dr * dr + gyz > lim);
-              const bool more_left = lo > s_run && !(dl > 0.f && dl * dl + gyz > lim);
-              if (dir == 0) go_left = more_left;
-              if (dir >= 0 && more_right) {
-                if (steps_r < kWalkBudget) {
-                  dir = 1;
-                  w = hi;
-                  hi += W;
-                  ++steps_r;
-                  continue;
-                }
-                rem_hi = hi;  // alive beyond the budget: queued below
-              }
-              if (dir >= 0 ? go_left : more_left) {
-                if (steps_l < kWalkBudget) {
-                  dir = -1;
-                  lo -= W;
-                  w = lo;
-                  ++steps_l;
-                  continue;
-                }
-                rem_lo = lo;
-              }
-              break;
-            }
-            if (improved) atomicMin(&S.qkey[qs], pack_key(ub, up));
-            if (a.dbg_qstats) {
-              atomicAdd(&S.qstat[qs][phase == 0 ? 0 : 2], (1 + steps_r + steps_l) * W);
-              if (side == 0 && phase == 0) atomicAdd(&S.qstat[qs][1], 1);
-            }
-            if (may_queue) {
-              constexpr int kChunk = (1 + kWalkBudget) * W;  // points a side task covers
-              const int cnt_max = lvl >= 1 ? 4 : 2;
-              if (rem_hi >= 0) {
-                const int cnt = min(cnt_max, (e_run - rem_hi + kChunk - 1) / kChunk);
-                if (!push_tasks(qs, 1, min(lvl + 1, 7), rem_hi, kChunk, e_run, gyz, cnt)) fb = true, fs = rem_hi, fe = e_run, fm = rem_hi;
-              }
-              if (rem_lo >= 0) {
-                const int cnt = min(cnt_max, (rem_lo - s_run + kChunk - 1) / kChunk);
-                if (fb) fs = s_run, fm = min(rem_lo, fe - 1);  // both sides: one walk over the whole run (part of it rescanned: harmless)
-                else if (!push_tasks(qs, 2, min(lvl + 1, 7), rem_lo - W, -kChunk, s_run, gyz, cnt)) fb = true, fs = s_run, fe = rem_lo, fm = rem_lo - 1;
-              }
-            }
-            }
-            if (fb) {
-              scan_global_outward(a.tgt, fs, fe, fm, q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
-              atomicMin(&S.qkey[qs], pack_key(ub, up));
-            }
+          const int u = atomicAdd(&S.q_head, 1);
+          if (u >= tail) break;
+          ++popped;
+          const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
+          const float gyz = S.unit_g[u];
+          const float4 q = S.qtab[qs];
+          const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
+          float ub = __uint_as_float((unsigned int)(k0 >> 32));
+          int up = (int)(unsigned int)k0;
+          if (gyz > fminf(ub, a.gate_sq_f)) continue;
+          const unsigned int c_before = ncand;
+          scan_global_outward(a.tgt, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          atomicMin(&S.qkey[qs], pack_key(ub, up));
+          if (a.dbg_qstats) {
+            atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
+            atomicAdd(&S.qstat[qs][1], 1);
           }
-          r_lo = r_hi;
         }
         NG_STAMP(17);
-        wave_lds_sync();
-        if (qok) {  // every query picks up what its windows found (which prunes its remaining rows in the next phase)
-          const unsigned long long k1 = S.qkey[grp];
-          best = __uint_as_float((unsigned int)(k1 >> 32));
-          pos = (int)(unsigned int)k1;
+        if (a.dbg_stamps) {
+          unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
+          atomicMax(&d[18], (unsigned long long)popped);
+          if (lane == 0) d[19] = (unsigned long long)tail;
+        }
+      }
+      wave_lds_sync();
+      if (qok) {
+        const unsigned long long k1 = S.qkey[grp];
+        best = __uint_as_float((unsigned int)(k1 >> 32));
+        pos = (int)(unsigned int)k1;
+      }
+      NG_STAMP(4);
+      float bound1 = 0.f;
+      if (qok) {
+        bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
+        went_far = !(best <= bound1 || bound1 >= a.gate_sq_f);
+      }
+      const unsigned int dbg_c1 = ncand;
+      unsigned int dbg_rows = 0;
+      // ---- rings 2..grow: units for the listed rows (nearest ring first) that can still hold a closer point, in rounds of
+      //      kUnitCap; between rounds every query picks up what its units found, which prunes its remaining rows ----
+      const bool need_far = in_box && went_far;
+      if (listed && __any(need_far)) {  // wave-uniform
+        int li = sub;
+        bool more = need_far;
+        for (;;) {
+          if (lane == 0) S.q_tail = 0, S.q_head = 0;
+          wave_lds_sync();
+          if (more) {
+            const float lim = fminf(best, a.gate_sq_f);
+            for (; li < nlive; li += G) {
+              const int4 rec = S.live[li];
+              if (row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz) > lim) continue;
+              const int slot = atomicAdd(&S.q_tail, 1);
+              if (slot >= kUnitCap) break;  // this row waits for the next round
+              S.unit_q[slot] = grp | (li << 5);
+              ++dbg_rows;
+            }
+            more = li < nlive;
+          }
+          wave_lds_sync();
+          {
+            const int tail = min(S.q_tail, kUnitCap);
+            for (;;) {
+              const int u = atomicAdd(&S.q_head, 1);
+              if (u >= tail) break;
+              const int unit = S.unit_q[u], qs = unit & 31;
+              const int4 rec = S.live[unit >> 5];
+              const float4 q = S.qtab[qs];
+              int ux, uy, uz;
+              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
+              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, uy, uz, q.y, q.z);
+              const unsigned long long k0 = S.qkey[qs];
+              float ub = __uint_as_float((unsigned int)(k0 >> 32));
+              int up = (int)(unsigned int)k0;
+              if (gyz > fminf(ub, a.gate_sq_f)) continue;
+              // start where qx sits among the row's three centre cells (one extra round trip, but a much better start
+              // than interpolating over the whole region row: the walk is over the whole row either way)
+              const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1;
+              const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
+              const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
+              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+              const unsigned int c_before = ncand;
+              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              atomicMin(&S.qkey[qs], pack_key(ub, up));
+              if (a.dbg_qstats) {
+                atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
+                atomicAdd(&S.qstat[qs][1], 1 << 16);
+              }
+            }
+          }
+          wave_lds_sync();
+          if (in_box) {
+            const unsigned long long k1 = S.qkey[grp];
+            best = __uint_as_float((unsigned int)(k1 >> 32));
+            pos = (int)(unsigned int)k1;
+          }
+          if (!__any(more)) break;
         }
       }
       NG_STAMP(5);
@@ -940,22 +824,25 @@ __global__ void __launch_bounds__(256, 3) k_gicp_pass(PassArgs a) {
         }
       }
     }
-    // ---- R0: per-batch reduction through LDS (the row tables are idle now): lanes 0..31 hold the tail's sums;
-    //      lane l writes row l of a [32][30] tile, lane v then adds column v in fixed order (deterministic).  A butterfly
-    //      of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips.
+    // ---- R0: per-batch reduction through LDS (the row tables are idle now): lanes 0..31 hold the tail's sums; sixteen of
+    //      them at a time write a row of a [16][30] tile, lane v then adds column v in fixed order (queries 0, 1, ... 31:
+    //      deterministic).  A butterfly of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips; a [32][30] tile
+    //      costs the LDS that a fourth block per CU needs.
     {
-      wave_lds_sync();
-      double* red = S.red;  // [32][30] doubles
-      if (lane < 32) {
+      double* red = S.red;  // [16][30] doubles
+      double out = 0.0;
 #pragma unroll
-        for (int v = 0; v < kNumSums; ++v) red[lane * 30 + v] = acc[v];
+      for (int half = 0; half < 2; ++half) {
+        wave_lds_sync();
+        if ((lane >> 4) == half) {
+#pragma unroll
+          for (int v = 0; v < kNumSums; ++v) red[(lane & 15) * 30 + v] = acc[v];
+        }
+        wave_lds_sync();
+        if (lane < kNumSums)
+          for (int l = 0; l < 16; ++l) out += red[l * 30 + lane];
       }
-      wave_lds_sync();
-      if (lane < kNumSums) {
-        double out = 0.0;
-        for (int l = 0; l < 32; ++l) out += red[l * 30 + lane];
-        wave_total += out;
-      }
+      if (lane < kNumSums) wave_total += out;
     }
   }
 
