@@ -123,7 +123,20 @@ BufPool& buf_pool() {
   static BufPool* p = new BufPool;
   return *p;
 }
-std::shared_ptr<DevBuf> acquire_buf(int device, size_t bytes) {
+// A recycled object may still be read by work that ANOTHER handle has in flight (a shared source index, a keyframe's covariance
+// set).  Instead of a device-wide, host-blocking hipDeviceSynchronize() the acquiring handle's stream waits - on the device - for
+// what every live handle of the same GPU has enqueued so far: one event record + one stream wait per handle (DLO has two).
+struct HandleRegistry {
+  std::mutex m;
+  std::vector<ngicp*> live;
+};
+HandleRegistry& registry() {
+  static HandleRegistry* r = new HandleRegistry;
+  return *r;
+}
+void fence_engine_streams(ngicp* h);  // defined below struct ngicp
+
+std::shared_ptr<DevBuf> acquire_buf(ngicp* h, int device, size_t bytes) {
   DevBuf* b = nullptr;
   {
     BufPool& bp = buf_pool();
@@ -139,7 +152,7 @@ std::shared_ptr<DevBuf> acquire_buf(int device, size_t bytes) {
     }
   }
   if (b) {
-    HIP_TRY(hipDeviceSynchronize());  // previous owners' work on other streams
+    fence_engine_streams(h);  // previous owners' work on other streams
   } else {
     b = new DevBuf;
     b->ensure(bytes);
@@ -152,7 +165,7 @@ std::shared_ptr<DevBuf> acquire_buf(int device, size_t bytes) {
   });
 }
 
-std::shared_ptr<DeviceCloud> acquire_cloud(int device) {
+std::shared_ptr<DeviceCloud> acquire_cloud(ngicp* h, int device) {
   DeviceCloud* dc = nullptr;
   {
     CloudPool& cp = cloud_pool();
@@ -166,7 +179,7 @@ std::shared_ptr<DeviceCloud> acquire_cloud(int device) {
   }
   if (dc) {
     // its previous owners may still have work in flight on their streams that reads the buffers
-    HIP_TRY(hipDeviceSynchronize());
+    fence_engine_streams(h);
     dc->n = 0;
     dc->has_inv = false;
     dc->n_batches = 0;
@@ -231,11 +244,11 @@ struct ngicp {
   hipStream_t stream = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_poll[2] = {nullptr, nullptr};
   hipEvent_t ev_cov_a = nullptr, ev_cov_b = nullptr;  // around the last covariance kernel; read lazily (ngicp_get_stats)
+  hipEvent_t ev_fence = nullptr;                       // fence_engine_streams()
   bool cov_timing_pending = false;
   std::string err;
   Params p;
   double voxel_size = 0.0;  // 0 = auto
-  int lanes_per_query = 0;  // 0 = auto
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
   int chunk_pairs = 4;      // (pass, solve) pairs enqueued between two polls of the done flag (env NGICP_CHUNK)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
@@ -279,6 +292,16 @@ struct ngicp {
 };
 
 namespace {
+
+void fence_engine_streams(ngicp* h) {
+  HandleRegistry& r = registry();
+  std::lock_guard<std::mutex> lock(r.m);
+  for (ngicp* o : r.live) {
+    if (o == h || o->device != h->device) continue;  // (work on h's own stream is ordered before anything h enqueues next)
+    HIP_TRY(hipEventRecord(h->ev_fence, o->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_fence, 0));
+  }
+}
 
 int pick_blocks(size_t work_items, int per_block, int max_blocks) {
   size_t b = (work_items + per_block - 1) / per_block;
@@ -374,7 +397,7 @@ void stage_host_cloud(ngicp* h, const float* xyz, size_t n, size_t stride, float
 
 // h->unsorted[0..n) -> an indexed DeviceCloud.  Everything stays on the device; one synchronisation at the end.
 std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3], const float mx[3]) {
-  auto dc = acquire_cloud(h->device);
+  auto dc = acquire_cloud(h, h->device);
   dc->n = n;
   for (int d = 0; d < 3; ++d) dc->bb_min[d] = mn[d], dc->bb_max[d] = mx[d];
   const int ni = (int)n;
@@ -525,7 +548,7 @@ void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
   const int k = h->p.k;
   if (k <= 0) throw ArgError{NGICP_ERR_ARG, "k must be positive"};
   if (k > 32 || (size_t)k > dc.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
-  auto buf = acquire_buf(h->device, dc.n * 6 * sizeof(double));
+  auto buf = acquire_buf(h, h->device, dc.n * 6 * sizeof(double));
   HIP_TRY(hipEventRecord(h->ev_cov_a, h->stream));
   const int reg = h->p.regularization;
   if (k <= 10)
@@ -548,7 +571,7 @@ const double* covs_for(ngicp* h, CovSet& cs, const std::shared_ptr<DeviceCloud>&
   // covariances are logically indexed by ORIGINAL point index (the reference's vector index):
   // re-order from the donor cloud's sorted order to this cloud's sorted order
   ensure_inv_perm(h, *cs.order);
-  auto buf = acquire_buf(h->device, dc->n * 6 * sizeof(double));
+  auto buf = acquire_buf(h, h->device, dc->n * 6 * sizeof(double));
   hipLaunchKernelGGL(k_covs_reorder, dim3((unsigned)((dc->n + 255) / 256)), dim3(256), 0, h->stream, cs.data->as<double>(), cs.order->inv_perm.as<int>(), dc->perm.as<int>(),
                      (int)dc->n, buf->as<double>());
   cs.data = buf;
@@ -577,7 +600,7 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
   ensure_slot_ready(h, slot, what);
   h->scratch16.ensure(n * 16 * sizeof(double));
   HIP_TRY(hipMemcpyAsync(h->scratch16.p, in, n * 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  auto buf = acquire_buf(h->device, n * 6 * sizeof(double));
+  auto buf = acquire_buf(h, h->device, n * 6 * sizeof(double));
   hipLaunchKernelGGL(k_covs_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->scratch16.as<double>(), slot.dev->perm.as<int>(), (int)n, buf->as<double>());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipGetLastError());
@@ -589,26 +612,14 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
 // ------------------------------------------------------------------------------------------
 // Registration loop
 // ------------------------------------------------------------------------------------------
-int auto_lanes(size_t n_src) {
-  // fill the chip (256 CUs x 2048 threads): cooperate more when there are few queries
-  if (n_src >= 1000000) return 2;
-  return 4;
-}
-
-template <int G>
-void launch_pass_t(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_gicp_pass<G>, dim3(nblocks), dim3(256), 0, s, a);
-}
-
-void launch_pass(ngicp* h, const PassArgs& a, int lanes, int nblocks, hipStream_t s) {
-  (void)lanes;
-  launch_pass_t<2>(h, a, nblocks, s);
+void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s) {
+  (void)h;
+  hipLaunchKernelGGL(k_gicp_pass<2>, dim3(nblocks), dim3(256), 0, s, a);  // 32-query batches, 2 lanes per query
 }
 
 struct LoopCtx {
   PassArgs pa;
   SolveArgs sa;
-  int lanes;
   int nblocks;
 };
 
@@ -625,11 +636,6 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
     h->tpt[i].ensure(n * sizeof(float4));
     h->mahal[i].ensure(n * 6 * sizeof(double));
   }
-  int lanes = h->lanes_per_query > 0 ? h->lanes_per_query : auto_lanes(n);
-  if (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16) lanes = 4;
-  const int groups_per_block = 256 / lanes;
-  (void)groups_per_block;
-  lanes = 2;  // the staged kernel is built for 32-query batches (2 lanes per query)
   const int nblocks = std::max(1, (S.n_batches + 3) / 4);  // one block per group of four batches
   h->partials.ensure((size_t)kNumSlots * nblocks * sizeof(double));
   h->grp_order.ensure((size_t)nblocks * sizeof(int));
@@ -693,9 +699,8 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.mode = 0;
   s.sums_out = nullptr;
   s.dbg_stamps = nullptr;
-  c.lanes = lanes;
   c.nblocks = nblocks;
-  h->stats.lanes_per_query = lanes;
+  h->stats.lanes_per_query = 2;
   h->stats.voxel_size = T.grid.h;
   h->stats.grid_dims[0] = T.grid.nx;
   h->stats.grid_dims[1] = T.grid.ny;
@@ -829,7 +834,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     for (int i = 0; i < chunk && launched < max_passes; ++i, ++launched) {
       const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
       if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched], h->stream));
-      launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+      launch_pass(h, c.pa, c.nblocks, h->stream);
       if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched + 1], h->stream));
       hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     }
@@ -989,6 +994,7 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipEventCreate(&h->ev_b));
     HIP_TRY(hipEventCreate(&h->ev_cov_a));
     HIP_TRY(hipEventCreate(&h->ev_cov_b));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_fence, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&h->ev_poll[0]));
     HIP_TRY(hipEventCreate(&h->ev_poll[1]));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_poll), 2 * sizeof(int), hipHostMallocDefault));
@@ -1000,9 +1006,13 @@ int ngicp_create(int device, ngicp_t** out) {
     for (int i = 0; i < 6; ++i) h->final_hessian[i * 6 + i] = 1.0;  // impl/lsq_registration_impl.hpp:62
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
-    if (const char* s = std::getenv("NGICP_LANES")) h->lanes_per_query = std::atoi(s);
     if (const char* s = std::getenv("NGICP_CHUNK")) h->chunk_pairs = std::max(1, std::min(64, std::atoi(s)));
     if (const char* s = std::getenv("NGICP_STAGE_GROW")) h->stage_grow = std::max(0, std::min(kStageMaxGrow, std::atoi(s)));
+    {
+      HandleRegistry& r = registry();
+      std::lock_guard<std::mutex> lock(r.m);
+      r.live.push_back(h.get());
+    }
     *out = h.release();
     return NGICP_OK;
   } catch (const HipError& e) {
@@ -1017,6 +1027,11 @@ int ngicp_create(int device, ngicp_t** out) {
 
 int ngicp_destroy(ngicp_t* h) {
   if (!h) return NGICP_OK;
+  {
+    HandleRegistry& r = registry();
+    std::lock_guard<std::mutex> lock(r.m);
+    r.live.erase(std::remove(r.live.begin(), r.live.end(), h), r.live.end());
+  }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->src.clear();
@@ -1031,6 +1046,7 @@ int ngicp_destroy(ngicp_t* h) {
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
   if (h->ev_cov_a) (void)hipEventDestroy(h->ev_cov_a);
   if (h->ev_cov_b) (void)hipEventDestroy(h->ev_cov_b);
+  if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
   for (int i = 0; i < 2; ++i)
     if (h->ev_poll[i]) (void)hipEventDestroy(h->ev_poll[i]);
   hipStream_t s = h->stream;
@@ -1065,7 +1081,6 @@ int ngicp_set_tuning(ngicp_t* h, double voxel_size, int lanes_per_query) {
     if (lanes_per_query != 0 && lanes_per_query != 1 && lanes_per_query != 2 && lanes_per_query != 4 && lanes_per_query != 8 && lanes_per_query != 16)
       throw ArgError{NGICP_ERR_ARG, "lanes_per_query must be 0,1,2,4,8 or 16"};
     h->voxel_size = voxel_size;
-    h->lanes_per_query = lanes_per_query;
   });
 }
 
@@ -1110,7 +1125,9 @@ int ngicp_share_source_index(ngicp_t* dst, ngicp_t* src) {
     // tree for its own cloud at impl/nano_gicp_impl.hpp:304-306)
     const bool same = (dst->src.identity != 0 && dst->src.identity == src->src.identity) || (dst->src.host == src->src.host && dst->src.n == src->src.n);
     if (same) {
-      HIP_TRY(hipStreamSynchronize(src->stream));
+      // dst's stream waits (on the device) for the index build src has enqueued: no host synchronisation per scan
+      HIP_TRY(hipEventRecord(dst->ev_fence, src->stream));
+      HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_fence, 0));
       dst->src.dev = src->src.dev;
     }
   });
@@ -1138,8 +1155,9 @@ int ngicp_copy_source_covs(ngicp_t* dst, ngicp_t* src) {
       dst->src_covs.clear();
       return;
     }
-    HIP_TRY(hipStreamSynchronize(src->stream));
     if (dst->device == src->device) {
+      HIP_TRY(hipEventRecord(dst->ev_fence, src->stream));  // the covariance kernel / reorder src has enqueued
+      HIP_TRY(hipStreamWaitEvent(dst->stream, dst->ev_fence, 0));
       dst->src_covs = src->src_covs;  // shares the immutable device buffer
     } else {
       throw ArgError{NGICP_ERR_ARG, "copy_source_covs across devices is not supported; use get/set"};
@@ -1205,7 +1223,7 @@ int ngicp_linearize(ngicp_t* h, const double T[16], double H[36], double b[6], d
     init_state_from_pose(st, pose_from_colmajor_d(T));
     HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
       c.pa.mode = 2 | 4;
-    launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+    launch_pass(h, c.pa, c.nblocks, h->stream);
     c.sa.mode = 1;
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     HIP_TRY(hipMemcpyAsync(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -1237,7 +1255,7 @@ int ngicp_compute_error(ngicp_t* h, const double T[16], double* err) {
     }
     HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
     c.pa.mode = 1 | 4;
-    launch_pass(h, c.pa, c.lanes, c.nblocks, h->stream);
+    launch_pass(h, c.pa, c.nblocks, h->stream);
     c.sa.mode = 2;
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     LmState st2;
@@ -1362,7 +1380,7 @@ int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* stream_or_null) {
     LoopCtx c;
     prepare_loop(h, c);
     c.pa.mode = ((h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3) | 4;
-    launch_pass(h, c.pa, c.lanes, c.nblocks, s);
+    launch_pass(h, c.pa, c.nblocks, s);
     c.sa.mode = 3;  // reduce only
     c.sa.sums_out = sums32_dev;
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
@@ -1515,7 +1533,7 @@ int ngicp_submap_set(ngicp_t* h, const int* ids, size_t n_ids, int* changed_out)
     }
     auto dc = index_unsorted(h, total, mn, mx);
     ensure_inv_perm(h, *dc);
-    auto buf = acquire_buf(h->device, total * 6 * sizeof(double));
+    auto buf = acquire_buf(h, h->device, total * 6 * sizeof(double));
     off = 0;
     for (size_t i = 0; i < n_ids; ++i) {
       const ngicp::Keyframe& kf = h->keyframes[(size_t)ids[i]];

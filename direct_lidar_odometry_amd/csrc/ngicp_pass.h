@@ -112,92 +112,11 @@ __device__ __forceinline__ void group_min(float& d, int& p) {
   }
 }
 
-// Scan one contiguous run of sorted target points (used by the rare outer shells).  Loads are issued
-// four at a time so that four memory latencies overlap; the tail batch re-reads the run's last point
-// (a duplicate can never win: equal distance AND equal position), so no per-load predicate is needed.
 // Nearest-neighbour candidates are ranked by (squared distance, sorted target position).  The reference
 // keeps the first point its kd-tree visits among exactly equidistant ones (impl/nanoflann_impl.hpp:184-211),
 // which no other index can mirror (SURVEY.md §7 "Ties"); a total order makes the winner independent of how
-// rows are dealt to lanes and of whether a candidate came from LDS or from global memory.
+// rows are dealt to lanes and of the order in which windows are looked at.
 __device__ __forceinline__ bool nn_better(float d, int p, float best, int bestp) { return d < best || (d == best && (unsigned)p < (unsigned)bestp); }
-
-__device__ __forceinline__ void scan_run_nn(const float4* __restrict__ tgt, int s, int e, float qx, float qy, float qz, float& best, int& pos) {
-  const int last = e - 1;
-  for (int p = s; p < e; p += 4) {
-    const int p1 = min(p + 1, last), p2 = min(p + 2, last), p3 = min(p + 3, last);
-    const float4 c0 = tgt[p], c1 = tgt[p1], c2 = tgt[p2], c3 = tgt[p3];
-    const float d0 = sqdist(qx, qy, qz, c0), d1 = sqdist(qx, qy, qz, c1), d2 = sqdist(qx, qy, qz, c2), d3 = sqdist(qx, qy, qz, c3);
-    // total order (distance, sorted position): the winner does not depend on the visiting order
-    if (nn_better(d0, p, best, pos)) { best = d0; pos = p; }
-    if (nn_better(d1, p1, best, pos)) { best = d1; pos = p1; }
-    if (nn_better(d2, p2, best, pos)) { best = d2; pos = p2; }
-    if (nn_better(d3, p3, best, pos)) { best = d3; pos = p3; }
-  }
-}
-
-// Scan up to NR runs as ONE virtual list, W loads in flight per step: the latency chain of a lane is
-// ceil(total / W) memory round trips, whatever the number of runs.
-template <int NR, int W>
-__device__ __forceinline__ void scan_runs_merged(const float4* __restrict__ tgt, const int (&rs)[NR], const int (&re)[NR], float qx, float qy, float qz, float& best,
-                                                 int& pos) {
-  int off[NR + 1];
-  off[0] = 0;
-#pragma unroll
-  for (int k = 0; k < NR; ++k) off[k + 1] = off[k] + (re[k] - rs[k]);
-  const int total = off[NR];
-  if (total == 0) return;
-  for (int f = 0; f < total; f += W) {
-    int idx[W];
-    float4 c[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const int g = min(f + j, total - 1);  // the tail repeats the last candidate (same distance and position: ignored)
-      int p = rs[0] + g;
-#pragma unroll
-      for (int k = 1; k < NR; ++k) p = (g >= off[k]) ? rs[k] + (g - off[k]) : p;
-      idx[j] = p;
-      c[j] = tgt[p];
-    }
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const float d = sqdist(qx, qy, qz, c[j]);
-      if (nn_better(d, idx[j], best, pos)) {
-        best = d;
-        pos = idx[j];
-      }
-    }
-  }
-}
-
-// Rings 0..1 without a row list (fallback when a batch's region does not fit the row table):
-// rows (fixed y,z; contiguous in x) are dealt round-robin to the G lanes of the group.
-template <int G>
-__device__ __forceinline__ void nn_ring1_global(const Grid& g, const float4* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                                int cx, int cy, int cz, int sub, float& best, int& pos, unsigned int& ncand) {
-  constexpr int NR = (9 + G - 1) / G;
-  const int xa = max(cx - 1, 0), xb = min(cx + 1, g.nx - 1);
-  int rs[NR], re[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {  // all row bounds first: the cell_start latencies overlap
-    const int t = sub + k * G;
-    const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-    const bool ok = (t < 9) && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
-    const int row = ok ? (z * g.ny + y) * g.nx : 0;
-    const int s = cell_start[row + xa], e = cell_start[row + xb + 1];
-    rs[k] = ok ? s : 0;
-    re[k] = ok ? e : 0;
-    ncand += (unsigned)(re[k] - rs[k]);
-  }
-  scan_runs_merged<NR, 8>(tgt, rs, re, qx, qy, qz, best, pos);
-  if (G > 1) group_min<G>(best, pos);
-}
-
-// --- reductions --------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 // --- the fused pass ------------------------------------------------------------------------------
 // Work decomposition: a wave owns ONE tile-aligned batch of up to 32 consecutive queries in Morton-tile order (a
@@ -228,7 +147,8 @@ constexpr int kStageXs = 20;         // cells per row of the region
 constexpr int kStageMaxGrow = 6;
 
 #ifndef NGICP_PASS_WAVES
-#define NGICP_PASS_WAVES 4  // waves per SIMD the pass kernel is compiled for (4: <= 128 VGPRs, four blocks of 40 KB LDS per CU)
+#define NGICP_PASS_WAVES 3  // waves per SIMD the pass kernel is compiled for.  4 fits (128 VGPRs with 7 spilled dwords, 40 KB LDS per block) and
+                            // was measured: c3 +7 %, c2 +3 %, c5 -3 % in time - twelve waves already saturate a CU's gather path
 #endif
 #ifndef NGICP_WALK_WINDOW
 #define NGICP_WALK_WINDOW 12

@@ -70,10 +70,10 @@ const char* ngicp_version(void);
  * setNumThreads impl/nano_gicp_impl.hpp:70-78 (accepted, meaningless on the GPU). */
 int ngicp_set_params(ngicp_t* h, int k, double max_corr_dist, int max_iter, double trans_eps, double rot_eps,
                      int optimizer, int lm_max_iter, double lm_init_lambda_factor, int regularization, int num_threads);
-/* engine knobs with no reference counterpart: voxel edge of the search grid in metres (0 = automatic: sized so that a
- * point sees ~24 points in its own cell) and lanes cooperating on one query in the per-iteration kernel (validated and
- * recorded; the current kernel always uses 2, which measured fastest).  Pure performance knobs: results do not depend
- * on them beyond the summation order. */
+/* engine knob with no reference counterpart: voxel edge of the search grid in metres (0 = automatic: sized so that a
+ * point sees ~24 points in its own cell).  A pure performance knob: the search is exact for any grid, so results do not
+ * depend on it beyond the summation order.  `lanes_per_query` is accepted for ABI stability (0, 1, 2, 4, 8 or 16) and
+ * ignored: the per-iteration kernel is built for 32-query batches with 2 lanes per query. */
 int ngicp_set_tuning(ngicp_t* h, double voxel_size, int lanes_per_query);
 
 /* --- clouds --------------------------------------------------------------- */

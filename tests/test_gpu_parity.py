@@ -425,8 +425,8 @@ def test_sharded_stepping_equals_single_align(ng):
 def test_full_size_properties(ng):
     w = clouds.scan_to_submap(100_000, 5)
     runs = []
-    for vox, lanes in ((0.0, 0), (0.2, 4), (0.35, 16)):
-        g = ng.NanoGICP(); g.setTuning(vox, lanes); g.setMaxCorrespondenceDistance(w.max_corr_dist)
+    for vox in (0.0, 0.2, 0.35):  # automatic voxel, then two fixed grids
+        g = ng.NanoGICP(); g.setTuning(vox); g.setMaxCorrespondenceDistance(w.max_corr_dist)
         g.setMaximumIterations(20); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
         g.setInputTarget(w.target); g.setInputSource(w.source)
         if not runs:
@@ -445,7 +445,7 @@ def test_full_size_properties(ng):
         runs.append((T1, tr1, g.nr_iterations_))
         s = g.stats()
         assert s["passes"] == s["lm_trials"] + 1 and 0.5 < s["valid_fraction"] <= 1.0
-    # grid resolution and lanes-per-query are pure performance knobs: exact search => identical results
+    # the grid resolution is a pure performance knob: exact search => identical results
     for T, tr, n in runs[1:]:
         assert np.array_equal(T, runs[0][0]) and np.array_equal(tr[:, [0, 1, 7]], runs[0][1][:, [0, 1, 7]]) and n == runs[0][2]
         # a different grid changes the summation order: the first iterations agree to rounding; later the 1e-12 pose
