@@ -224,6 +224,9 @@ struct Slot {
   }
 };
 
+struct LoopCtx;  // the per-alignment launch arguments (defined with the registration loop)
+constexpr int kShardSlots = 4, kShardLag = 2;  // point-sharded stepping: the `done` word of step k is read at step k + kShardLag
+
 struct Params {
   int k = 20;                                                       // impl/nano_gicp_impl.hpp:57
   double max_corr_dist = (double)std::numeric_limits<float>::max(); // :59
@@ -280,6 +283,11 @@ struct ngicp {
 
   // sharded stepping
   bool sharded_active = false;
+  std::shared_ptr<LoopCtx> shard_ctx;      // the loop context of the alignment being stepped (one prepare_loop per alignment)
+  hipEvent_t ev_shard[kShardSlots] = {};   // behind the copy of the `done` word of step k (slot k mod kShardSlots)
+  int* h_shard_done = nullptr;             // pinned [kShardSlots]
+  long shard_steps = 0;
+  hipStream_t shard_stream = nullptr;      // the stream the last step was enqueued on
 
   // device-resident keyframe store (src/dlo/odom.cc keyframes + keyframe_normals) and the submap assembled from it
   struct Keyframe {
@@ -1000,6 +1008,11 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_poll), 2 * sizeof(int), hipHostMallocDefault));
     h->h_poll[0] = h->h_poll[1] = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_state), 2 * sizeof(LmState), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_shard_done), kShardSlots * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < kShardSlots; ++i) {
+      h->h_shard_done[i] = 0;
+      HIP_TRY(hipEventCreateWithFlags(&h->ev_shard[i], hipEventDisableTiming));
+    }
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     std::memcpy(h->final_T, I, sizeof(I));
     std::memset(h->final_hessian, 0, sizeof(h->final_hessian));
@@ -1042,6 +1055,9 @@ int ngicp_destroy(ngicp_t* h) {
     if (e) (void)hipEventDestroy(e);
   if (h->h_poll) (void)hipHostFree(h->h_poll);
   if (h->pin_state) (void)hipHostFree(h->pin_state);
+  if (h->h_shard_done) (void)hipHostFree(h->h_shard_done);
+  for (auto& e : h->ev_shard)
+    if (e) (void)hipEventDestroy(e);
   if (h->ev_a) (void)hipEventDestroy(h->ev_a);
   if (h->ev_b) (void)hipEventDestroy(h->ev_b);
   if (h->ev_cov_a) (void)hipEventDestroy(h->ev_cov_a);
@@ -1357,16 +1373,26 @@ int ngicp_set_profiling(ngicp_t* h, int on) {
 }
 
 // ---- point-sharded stepping ----
+// One loop context per alignment (ngicp_sharded_begin); per pass two small launches around the caller's all-reduce (the pass +
+// a reduce-only solver, then the solver proper on the reduced vector); no host synchronisation per pass: the `done` word of
+// step k is copied to pinned memory behind an event and READ AT STEP k + kShardLag.  The lag is a constant, so every rank
+// takes the same decision in the same step (a rank that stopped calling the collective earlier than its peers would hang them);
+// the extra kShardLag passes after the end are no-ops (both kernels return at once when the state says done).
 int ngicp_sharded_begin(ngicp_t* h, const float guess[16]) {
   return guarded(h, [&] {
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    LoopCtx c;
+    h->shard_ctx.reset(new LoopCtx);
+    LoopCtx& c = *h->shard_ctx;
     prepare_loop(h, c);
+    c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
     LmState st;
     init_state_from_pose(st, pose_from_colmajor_f(guess ? guess : I));
     if (h->p.max_iter <= 0) st.hot.done = 1;
-    HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
+    h->pin_state[0] = st;
+    HIP_TRY(hipMemcpyAsync(h->state.p, &h->pin_state[0], sizeof(st), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));  // once per alignment: the caller may step on a stream of its own
+    for (int i = 0; i < kShardSlots; ++i) h->h_shard_done[i] = 0;
+    h->shard_steps = 0;
     h->sharded_active = true;
     h->hook_valid = 0;
   });
@@ -1374,53 +1400,69 @@ int ngicp_sharded_begin(ngicp_t* h, const float guess[16]) {
 
 int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* stream_or_null) {
   return guarded(h, [&] {
-    if (!h->sharded_active) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
+    if (!h->sharded_active || !h->shard_ctx) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
     if (!sums32_dev) throw ArgError{NGICP_ERR_ARG, "null sums buffer"};
     hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : h->stream;
-    LoopCtx c;
-    prepare_loop(h, c);
-    c.pa.mode = ((h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3) | 4;
+    LoopCtx& c = *h->shard_ctx;
     launch_pass(h, c.pa, c.nblocks, s);
-    c.sa.mode = 3;  // reduce only
-    c.sa.sums_out = sums32_dev;
-    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
+    SolveArgs sa = c.sa;
+    sa.mode = 3;  // reduce only: this rank's 32 sums, for the caller's all-reduce
+    sa.sums_out = sums32_dev;
+    sa.grp_order = nullptr;
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, sa);
     HIP_TRY(hipGetLastError());
   });
 }
 
 int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* stream_or_null, int* done) {
   return guarded(h, [&] {
-    if (!h->sharded_active) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
+    if (!h->sharded_active || !h->shard_ctx) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
+    if (!sums32_dev) throw ArgError{NGICP_ERR_ARG, "null sums buffer"};
     hipStream_t s = stream_or_null ? (hipStream_t)stream_or_null : h->stream;
-    LoopCtx c;
-    prepare_loop(h, c);
-    c.sa.mode = 0;
-    c.sa.partials = sums32_dev;  // one pre-reduced vector
-    c.sa.nblocks = 1;
-    c.sa.grp_order = nullptr;  // the vector is one pre-reduced column, not per-group partials
-    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, c.sa);
+    LoopCtx& c = *h->shard_ctx;
+    SolveArgs sa = c.sa;
+    sa.mode = 0;
+    sa.partials = sums32_dev;  // one pre-reduced row
+    sa.nblocks = 1;
+    sa.grp_order = nullptr;    // (the launch order of the pass is per rank and is left alone)
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, s, sa);
+    h->shard_stream = s;
+    const long k = h->shard_steps++;
+    const int slot = (int)(k % kShardSlots);
     LmState* dst = h->state.as<LmState>();
-    HIP_TRY(hipMemcpyAsync(&h->h_poll[0], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpyAsync(&h->h_shard_done[slot], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(h->ev_shard[slot], s));
     HIP_TRY(hipGetLastError());
-    if (done) *done = h->h_poll[0];
+    int d = 0;
+    if (k >= kShardLag) {  // the flag of step k - kShardLag: its copy finished long ago, the wait does not stall the stream
+      const int old = (int)((k - kShardLag) % kShardSlots);
+      HIP_TRY(hipEventSynchronize(h->ev_shard[old]));
+      d = h->h_shard_done[old];
+    }
+    if (done) *done = d;
   });
 }
 
 int ngicp_sharded_finish(ngicp_t* h, float T_out[16], int* converged, int* nr_iterations, double final_hessian[36]) {
   return guarded(h, [&] {
-    LmState st;
-    HIP_TRY(hipMemcpy(&st, h->state.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (!h->sharded_active) throw ArgError{NGICP_ERR_STATE, "ngicp_sharded_begin not called"};
+    hipStream_t s = h->shard_stream ? h->shard_stream : h->stream;  // the steps were enqueued there
+    HIP_TRY(hipMemcpyAsync(&h->pin_state[1], h->state.p, sizeof(LmState), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const LmState& st = h->pin_state[1];
     pose_to_colmajor_f(st.hot.x0, h->final_T);
     h->converged = st.hot.converged;
     h->nr_iterations = st.hot.nr_iterations;
     for (int r = 0; r < 6; ++r)
       for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.final_hessian[r * 6 + cc];
+    if (st.hot.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // impl/lsq_registration_impl.hpp:106
     if (T_out) std::memcpy(T_out, h->final_T, sizeof(h->final_T));
     if (converged) *converged = h->converged;
     if (nr_iterations) *nr_iterations = h->nr_iterations;
     if (final_hessian) std::memcpy(final_hessian, h->final_hessian, sizeof(h->final_hessian));
     h->sharded_active = false;
+    h->shard_ctx.reset();
+    h->shard_stream = nullptr;
   });
 }
 

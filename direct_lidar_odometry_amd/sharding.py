@@ -67,16 +67,28 @@ def gather_results(T_local: list[np.ndarray], dist, device=None):
     return [o[: int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]
 
 
-def sharded_align(engine, guess, dist, torch_device):
-    """Point-sharded alignment on the HIP engine.  `engine` already holds this rank's source block, the
-    full target and both covariance sets.  Returns the final 4x4 (identical on every rank)."""
+MAX_SHARDED_PASSES = 64 * 10 + 8  # max_iterations x lm_max_iterations of the reference's defaults, plus the reporting lag
+
+
+def sharded_align(engine, guess, dist, torch_device, max_passes: int = MAX_SHARDED_PASSES):
+    """Point-sharded alignment.  `engine` already holds this rank's source block, the full target and both
+    covariance sets; it offers sharded_begin / sharded_pass / sharded_step / sharded_finish (the HIP engine's
+    NanoGICP, or any stand-in with the same protocol).  Per pass: the engine leaves its 32 partial sums in `sums`
+    (device memory on the GPU node), ONE all-reduce adds the ranks' sums (what is reduced is the reference's own
+    per-thread partial sum, impl/nano_gicp_impl.hpp:260-267), every rank advances the identical LM state machine.
+    The engine reports `done` with a constant lag, identically on every rank, so all ranks leave the loop in the
+    same step.  Returns the final 4x4 (identical on every rank)."""
     import torch
-    sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=torch_device)
-    stream = torch.cuda.current_stream(torch_device).cuda_stream
+    dev = torch.device(torch_device)
+    sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=dev)
+    # the engine's kernels go onto torch's current stream, the stream the collective is ordered on
+    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
     engine.sharded_begin(guess)
-    while True:
+    for _ in range(max_passes):
         engine.sharded_pass(sums.data_ptr(), stream)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         if engine.sharded_step(sums.data_ptr(), stream):
             break
+    else:
+        raise RuntimeError("sharded_align: the alignment did not report completion")  # (bounded: a hang would take the node)
     return engine.sharded_finish()

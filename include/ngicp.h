@@ -168,11 +168,15 @@ int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
 int ngicp_set_profiling(ngicp_t* h, int on);
 
 /* --- point-sharded multi-GPU stepping ------------------------ */
-/* One GICP pass over this handle's source block at the engine's current trial pose: writes 32 doubles
- * {H upper-tri 21, b 6, y0, yi, candidates tested, valid correspondences, staged queries} to device memory
- * `sums32_dev` (caller all-reduces them, e.g. RCCL via torch.distributed: 256 B, latency-bound), then
- * ngicp_sharded_step consumes the reduced sums and advances the LM state machine identically on every
- * rank.  *done is set when the alignment finished. */
+/* One alignment whose SOURCE points are split over ranks (each rank's handle holds its block of the source, the whole target
+ * and both covariance sets).  Per pass: ngicp_sharded_pass runs the fused pass over this rank's block at the engine's current
+ * trial pose and leaves 32 doubles {H upper-tri 21, b 6, y0, yi, candidates tested, valid correspondences, listed queries} in
+ * device memory `sums32_dev`; the caller all-reduces them (RCCL through torch.distributed: 256 B, latency-bound);
+ * ngicp_sharded_step feeds the reduced sums to the LM state machine, which advances identically on every rank (what is
+ * reduced is the reference's own per-thread partial sum, impl/nano_gicp_impl.hpp:260-267).  Nothing synchronises the host per
+ * pass: *done reports the state as of TWO steps earlier (a constant lag, so that every rank leaves the loop in the same step -
+ * a rank that stopped calling the collective before its peers would hang them); the two passes after the end do nothing.
+ * All calls of one alignment must use the same stream (NULL: the handle's own). */
 int ngicp_sharded_begin(ngicp_t* h, const float guess_colmajor[16]);
 int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* hip_stream_or_null);
 int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* hip_stream_or_null, int* done);

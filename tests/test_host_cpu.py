@@ -125,3 +125,133 @@ def test_two_rank_gloo_sharded_reduction_and_gather(oracle_mod):
     for rank, ok, n_total, shapes in res:
         assert ok, f"rank {rank}: all-reduced H/b/err differ from the unsharded linearisation"
         assert n_total == 3 and shapes == [(2, 4, 4), (1, 4, 4)]
+
+
+# ------------------------------------------------------------------ point-sharded alignment over gloo
+class _OracleShardEngine:
+    """A CPU stand-in for the HIP engine's sharded protocol (sharded_begin / pass / step / finish, include/ngicp.h), built on the
+    oracle's linearize / compute_error hooks: `pass` leaves {H, b, y0 of a linearisation at the trial pose; yi = error of the trial
+    pose under the previous correspondences} in the caller's buffer, `step` advances LsqRegistration's LM state machine
+    (impl/lsq_registration_impl.hpp:161-208) on the all-reduced sums and reports `done` with the engine's constant lag of two steps.
+    It exists so that sharding.sharded_align - the code that runs over RCCL on the GPU node - is executed and checked here."""
+    LAG = 2
+
+    def __init__(self, orc, src_block, tgt, cov_src_block, cov_tgt, max_corr, max_iter=64, trans_eps=5e-4, rot_eps=2e-3):
+        from oracle import oracle as om
+        self.om = om
+        self.o = orc.OracleGICP(); self.o.setNumThreads(1); self.o.setMaxCorrespondenceDistance(max_corr)
+        self.o.setInputSource(src_block); self.o.setInputTarget(tgt)
+        self.o.setSourceCovariances(cov_src_block); self.o.setTargetCovariances(cov_tgt)
+        self.max_iter, self.trans_eps, self.rot_eps = max_iter, trans_eps, rot_eps
+
+    @staticmethod
+    def _view(ptr):
+        return np.ctypeslib.as_array((ctypes.c_double * 32).from_address(ptr))
+
+    def sharded_begin(self, guess):
+        self.x0 = np.asarray(np.eye(4) if guess is None else guess, np.float32).astype(np.float64)
+        self.xi = self.x0.copy()
+        self.have_lin, self.lam, self.nu, self.iter, self.trial = False, -1.0, 2.0, 0, 0
+        self.done, self.converged, self.nr_iterations = False, False, 0
+        self.flags = []
+
+    def sharded_pass(self, ptr, stream=0):
+        from direct_lidar_odometry_amd import sharding as sh
+        v = self._view(ptr)
+        if self.done:
+            return
+        yi = self.o.compute_error(self.xi) if self.have_lin else 0.0   # K4: previous correspondences (stale on purpose)
+        H, b, y0 = self.o.linearize(self.xi)                           # K2 + K3, speculative: adopted when the trial is accepted
+        v[:] = sh.pack_sums(H, b, y0, yi)
+
+    def _trial(self):
+        d = self.om.ldlt6_solve(self.H + self.lam * np.eye(6), -self.b)
+        self.d = d
+        self.delta = np.eye(4); self.delta[:3, :3] = self.om.so3_exp(d[:3]); self.delta[:3, 3] = d[3:]
+        self.xi = self.delta @ self.x0
+
+    def _is_converged(self):
+        return max((np.abs(self.delta[:3, :3] - np.eye(3)) / self.rot_eps).max(), (np.abs(self.delta[:3, 3]) / self.trans_eps).max()) < 1
+
+    def sharded_step(self, ptr, stream=0) -> bool:
+        from direct_lidar_odometry_amd import sharding as sh
+        if not self.done:
+            H, b, y0, yi = sh.unpack_sums(self._view(ptr))
+            if not self.have_lin:
+                self.H, self.b, self.y0, self.have_lin = H, b, y0, True
+                self.lam = 1e-9 * np.abs(np.diag(H)).max()
+                self._trial()
+            else:
+                rho = (self.y0 - yi) / (self.d @ (self.lam * self.d - self.b))
+                if rho < 0:  # rejected: the reference keeps x0 and its linearisation (the oracle's correspondences moved: restore them)
+                    if self._is_converged():
+                        self.converged = self.done = True
+                    else:
+                        self.lam *= self.nu; self.nu *= 2; self.trial += 1
+                        if self.trial >= 10:
+                            self.done = True
+                        else:
+                            self.o.linearize(self.x0); self._trial()
+                else:
+                    self.x0 = self.xi
+                    self.lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+                    self.converged = self._is_converged()
+                    self.iter += 1
+                    if self.converged or self.iter >= self.max_iter:
+                        self.done = True
+                    else:
+                        self.H, self.b, self.y0 = H, b, y0
+                        self.nr_iterations, self.nu, self.trial = self.iter, 2.0, 0
+                        self._trial()
+        self.flags.append(self.done)
+        return self.flags[-1 - self.LAG] if len(self.flags) > self.LAG else False
+
+    def sharded_finish(self):
+        return self.x0.astype(np.float32)
+
+
+def _gloo_sharded_align_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from direct_lidar_odometry_amd import sharding as sh
+        from oracle import oracle as orc
+        with np.load(os.path.join(ROOT, "tests", "golden", "ngicp_small.npz")) as z:
+            src, tgt, guess = z["source"], z["target"], z["guess"]
+            T_ref, it_ref = z["final_T"], int(z["nr_iterations"])
+        full = orc.OracleGICP(); full.setNumThreads(1); full.setMaxCorrespondenceDistance(1.0); full.setInputSource(src); full.setInputTarget(tgt)
+        full.calculateSourceCovariances(); full.calculateTargetCovariances()
+        cs, ct = full.getSourceCovariances(), full.getTargetCovariances()
+        lo, hi = sh.shard_bounds(len(src), world, rank)
+        e = _OracleShardEngine(orc, src[lo:hi], tgt, cs[lo:hi], ct, 1.0)
+        T = sh.sharded_align(e, guess, dist, torch.device("cpu"))
+        # every rank must end on the identical pose without a broadcast
+        t = torch.from_numpy(T.astype(np.float64).copy()); ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        same = all(torch.equal(ts[0], x) for x in ts)
+        q.put((rank, T, e.nr_iterations, e.converged, bool(same), len(e.flags), T_ref, it_ref))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_point_sharded_align(oracle_mod):
+    """sharding.sharded_align (the driver of the RCCL path) run for real over gloo, 2 ranks: source points split, one 256-byte
+    all-reduce per pass, identical LM state machine on both ranks - against the unsharded alignment of the golden fixture."""
+    import torch.multiprocessing as mp
+    from direct_lidar_odometry_amd import clouds
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_sharded_align_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, T, nit, conv, same, steps, T_ref, it_ref in res:
+        assert same, "ranks ended on different poses"
+        dt, dr = clouds.pose_error(T, T_ref)
+        assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)         # the sharded sums differ from the unsharded ones only in summation order
+        assert nit == it_ref and conv
+        assert steps == (it_ref + 1) + 1 + _OracleShardEngine.LAG  # one pass per LM trial + the first linearisation + the reporting lag
