@@ -19,6 +19,7 @@
 
 #include "ngicp_pass.h"
 #include "ngicp_cloudops.h"
+#include "ngicp_filters.h"
 
 using namespace ngk;
 
@@ -288,6 +289,13 @@ struct ngicp {
   int* h_shard_done = nullptr;             // pinned [kShardSlots]
   long shard_steps = 0;
   hipStream_t shard_stream = nullptr;      // the stream the last step was enqueued on
+
+  // scan preprocessing / map voxel filter
+  FilterWorkspace fws;
+  DevBuf xyzi, map_pts;      // the unpacked input of a filter call; the accumulated map, float4 {x, y, z, intensity}
+  size_t map_n = 0;
+  const float4* filt_out = nullptr;  // result of the last preprocess call (device memory of fws / xyzi), filt_n points
+  int filt_n = 0;
 
   // device-resident keyframe store (src/dlo/odom.cc keyframes + keyframe_normals) and the submap assembled from it
   struct Keyframe {
@@ -1065,6 +1073,7 @@ int ngicp_destroy(ngicp_t* h) {
   if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
   for (int i = 0; i < 2; ++i)
     if (h->ev_poll[i]) (void)hipEventDestroy(h->ev_poll[i]);
+  ngk_filter_free(&h->fws);
   hipStream_t s = h->stream;
   delete h;
   if (s) (void)hipStreamDestroy(s);
@@ -1661,6 +1670,139 @@ int ngicp_measure_copy_bandwidth(ngicp_t* h, size_t bytes, int reps, double* gbp
     HIP_TRY(hipGetLastError());
     *gbps_out = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;  // read + write
   });
+}
+
+}  // extern "C"
+
+// ---- scan preprocessing and map accumulation + voxel filter ----
+namespace {
+// host cloud (strided xyz [+ intensity]) -> device float4 {x, y, z, intensity} at dst[0..n)
+void upload_xyzi(ngicp* h, const float* pts, size_t n, size_t stride, long intensity_off, float4* dst) {
+  if (stride < 12 || stride % 4) throw ArgError{NGICP_ERR_ARG, "stride_bytes must be a multiple of 4 and >= 12"};
+  if (intensity_off >= 0 && ((size_t)intensity_off + 4 > stride || intensity_off % 4)) throw ArgError{NGICP_ERR_ARG, "intensity offset outside the point stride"};
+  if (n > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "cloud too large for int indices"};
+  const size_t raw_bytes = (n - 1) * stride + (intensity_off >= 0 ? std::max((size_t)12, (size_t)intensity_off + 4) : 12);
+  h->raw.ensure(raw_bytes);
+  HIP_TRY(hipMemcpyAsync(h->raw.p, pts, raw_bytes, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_unpack_xyzi, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->raw.as<unsigned char>(), stride, intensity_off, (int)n, dst);
+}
+void download_xyzi(ngicp* h, const float4* src, size_t n, float* out) {
+  if (n == 0) return;
+  HIP_TRY(hipMemcpyAsync(out, src, n * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+}
+}  // namespace
+
+extern "C" {
+
+int ngicp_preprocess_scan(ngicp_t* h, const float* pts, size_t n, size_t stride_bytes, long intensity_offset_bytes, int remove_nan, float crop_half_extent,
+                          float voxel_leaf, float* out_xyzi, size_t out_capacity, size_t* n_out) {
+  return guarded(h, [&] {
+    if (n_out) *n_out = 0;
+    h->filt_out = nullptr;
+    h->filt_n = 0;
+    if (n == 0) return;
+    if (!pts) throw ArgError{NGICP_ERR_ARG, "null cloud pointer"};
+    h->xyzi.ensure(n * sizeof(float4));
+    upload_xyzi(h, pts, n, stride_bytes, intensity_offset_bytes, h->xyzi.as<float4>());
+    char err[256] = {0};
+    const float4* out = nullptr;
+    int m = 0;
+    if (ngk_filter_cloud(h->stream, &h->fws, h->xyzi.as<float4>(), (int)n, remove_nan, crop_half_extent, voxel_leaf, &out, &m, err, sizeof(err)))
+      throw ArgError{NGICP_ERR_HIP, err};
+    h->filt_out = out;
+    h->filt_n = m;
+    if (n_out) *n_out = (size_t)m;
+    if (out_xyzi) {
+      if ((size_t)m > out_capacity) throw ArgError{NGICP_ERR_ARG, "output buffer too small for the filtered cloud"};
+      download_xyzi(h, out, (size_t)m, out_xyzi);
+    }
+  });
+}
+
+int ngicp_set_source_preprocessed(ngicp_t* h, uint64_t host_identity) {
+  int rc = guarded(h, [&] {
+    if (!h->filt_out || h->filt_n <= 0) throw ArgError{NGICP_ERR_STATE, "no preprocessed cloud: call ngicp_preprocess_scan first"};
+    const size_t n = (size_t)h->filt_n;
+    h->unsorted.ensure(n * sizeof(float4));
+    const int bbox_blocks = pick_blocks(n, 1024, 512);
+    h->bbox.ensure((size_t)bbox_blocks * 8 * sizeof(float));
+    hipLaunchKernelGGL(k_xyzi_to_unsorted, dim3(bbox_blocks), dim3(256), 0, h->stream, h->filt_out, (int)n, h->unsorted.as<float4>(), h->bbox.as<float>());
+    std::vector<float> bb((size_t)bbox_blocks * 8);
+    HIP_TRY(hipMemcpyAsync(bb.data(), h->bbox.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int b = 0; b < bbox_blocks; ++b)
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = std::min(mn[d], bb[(size_t)b * 8 + d]);
+        mx[d] = std::max(mx[d], bb[(size_t)b * 8 + 3 + d]);
+      }
+    for (int d = 0; d < 3; ++d)
+      if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || mn[d] > mx[d]) throw ArgError{NGICP_ERR_ARG, "preprocessed cloud contains non-finite coordinates (filter it with remove_nan)"};
+    auto dc = index_unsorted(h, n, mn, mx);
+    h->src.clear();  // setInputSource (impl/nano_gicp_impl.hpp:121-129) with a cloud that is already on the device
+    h->src.present = true;
+    h->src.n = n;
+    h->src.identity = host_identity;
+    h->src.dev = dc;
+    h->src_covs.clear();
+  });
+  return rc;
+}
+
+int ngicp_map_add(ngicp_t* h, const float* pts, size_t n, size_t stride_bytes, long intensity_offset_bytes) {
+  return guarded(h, [&] {
+    if (n == 0) return;
+    if (!pts) throw ArgError{NGICP_ERR_ARG, "null cloud pointer"};
+    if (h->map_n + n > (size_t)0x7fffff00) throw ArgError{NGICP_ERR_ARG, "map too large for int indices"};
+    if ((h->map_n + n) * sizeof(float4) > h->map_pts.cap) {  // grow, keeping what is there (`*dlo_map += *keyframe`, map.cc:129)
+      DevBuf bigger;
+      bigger.ensure((h->map_n + n) * 2 * sizeof(float4));
+      if (h->map_n) HIP_TRY(hipMemcpyAsync(bigger.p, h->map_pts.p, h->map_n * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      std::swap(bigger.p, h->map_pts.p);
+      std::swap(bigger.cap, h->map_pts.cap);
+    }
+    upload_xyzi(h, pts, n, stride_bytes, intensity_offset_bytes, h->map_pts.as<float4>() + h->map_n);
+    h->map_n += n;
+    HIP_TRY(hipGetLastError());
+  });
+}
+
+int ngicp_map_voxel_filter(ngicp_t* h, float leaf, size_t* n_out) {
+  return guarded(h, [&] {
+    if (n_out) *n_out = h->map_n;
+    if (h->map_n == 0 || !(leaf > 0.f)) return;
+    char err[256] = {0};
+    const float4* out = nullptr;
+    int m = 0;
+    // voxelgrid.setInputCloud(dlo_map); voxelgrid.filter(*dlo_map)  (map.cc:102-104): the map is replaced by its centroids
+    if (ngk_filter_cloud(h->stream, &h->fws, h->map_pts.as<float4>(), (int)h->map_n, 0, 0.f, leaf, &out, &m, err, sizeof(err))) throw ArgError{NGICP_ERR_HIP, err};
+    if (out != h->map_pts.as<float4>()) {
+      HIP_TRY(hipMemcpyAsync(h->map_pts.p, out, (size_t)m * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->map_n = (size_t)m;
+    if (n_out) *n_out = h->map_n;
+  });
+}
+
+int ngicp_map_size(const ngicp_t* h, size_t* n) {
+  if (!h || !n) return NGICP_ERR_ARG;
+  *n = h->map_n;
+  return NGICP_OK;
+}
+
+int ngicp_map_get(ngicp_t* h, float* out_xyzi, size_t out_capacity) {
+  return guarded(h, [&] {
+    if (!out_xyzi) throw ArgError{NGICP_ERR_ARG, "null output"};
+    if (h->map_n > out_capacity) throw ArgError{NGICP_ERR_ARG, "output buffer too small for the map"};
+    download_xyzi(h, h->map_pts.as<float4>(), h->map_n, out_xyzi);
+  });
+}
+
+int ngicp_map_clear(ngicp_t* h) {
+  return guarded(h, [&] { h->map_n = 0; });
 }
 
 }  // extern "C"

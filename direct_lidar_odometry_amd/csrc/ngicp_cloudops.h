@@ -108,6 +108,51 @@ __global__ void __launch_bounds__(256) k_transform_raw(const unsigned char* __re
   d[0] = o.x; d[1] = o.y; d[2] = o.z;
 }
 
+// raw strided host layout (already on the device) -> float4 {x, y, z, intensity} (intensity 0 when the layout has none)
+__global__ void __launch_bounds__(256) k_unpack_xyzi(const unsigned char* __restrict__ raw, size_t stride_bytes, long intensity_offset, int n, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned char* b = raw + (size_t)i * stride_bytes;
+  const float* p = reinterpret_cast<const float*>(b);
+  out[i] = make_float4(p[0], p[1], p[2], intensity_offset >= 0 ? *reinterpret_cast<const float*>(b + intensity_offset) : 0.f);
+}
+
+// filtered cloud {x, y, z, intensity} -> the index build's staging array {x, y, z, bitcast(index)} + per-block bounding-box partials
+__global__ void __launch_bounds__(256) k_xyzi_to_unsorted(const float4* __restrict__ in, int n, float4* __restrict__ unsorted, float* __restrict__ bbox_part) {
+  __shared__ float lds[4][6];
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 p = in[i];
+    unsorted[i] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lds[wave][d] = mn[d];
+      lds[wave][3 + d] = mx[d];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    float v = lds[0][d];
+    for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, lds[w][d]) : fmaxf(v, lds[w][d]);
+    bbox_part[blockIdx.x * 8 + d] = v;
+  }
+}
+
 // device stream copy (the measured copy bandwidth reported next to the nominal HBM peak): one block moves a
 // contiguous 16 KiB piece, four float4 per thread in flight
 __global__ void __launch_bounds__(256) k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {

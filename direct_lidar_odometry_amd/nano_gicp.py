@@ -71,6 +71,8 @@ EXPORTS = [
     "ngicp_sharded_pass", "ngicp_sharded_step", "ngicp_sharded_finish",
     "ngicp_keyframe_add", "ngicp_keyframe_add_transformed", "ngicp_keyframe_count", "ngicp_keyframe_size", "ngicp_keyframe_clear",
     "ngicp_submap_set", "ngicp_get_target_points", "ngicp_transform_source", "ngicp_transform_cloud", "ngicp_measure_copy_bandwidth",
+    "ngicp_preprocess_scan", "ngicp_set_source_preprocessed", "ngicp_map_add", "ngicp_map_voxel_filter", "ngicp_map_size", "ngicp_map_get",
+    "ngicp_map_clear",
 ]
 
 _lib = None
@@ -131,6 +133,13 @@ def load_library() -> C.CDLL:
     L.ngicp_transform_source.argtypes = [vp, c_f32p, c_f32p, C.c_size_t]
     L.ngicp_transform_cloud.argtypes = [vp, c_f32p, C.c_size_t, C.c_size_t, c_f32p, c_f32p, C.c_size_t]
     L.ngicp_measure_copy_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, c_f64p]
+    L.ngicp_preprocess_scan.argtypes = [vp, c_f32p, C.c_size_t, C.c_size_t, C.c_long, C.c_int, C.c_float, C.c_float, c_f32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.ngicp_set_source_preprocessed.argtypes = [vp, C.c_uint64]
+    L.ngicp_map_add.argtypes = [vp, c_f32p, C.c_size_t, C.c_size_t, C.c_long]
+    L.ngicp_map_voxel_filter.argtypes = [vp, C.c_float, C.POINTER(C.c_size_t)]
+    L.ngicp_map_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+    L.ngicp_map_get.argtypes = [vp, c_f32p, C.c_size_t]
+    L.ngicp_map_clear.argtypes = [vp]
     _lib = L
     return L
 
@@ -406,6 +415,50 @@ class NanoGICP:
         out = np.empty((c.shape[0], 3), dtype=np.float32)
         self._ck(self._L.ngicp_transform_cloud(self._h, _p(c, c_f32p), c.shape[0], c.strides[0], _p(t, c_f32p), _p(out, c_f32p), 12))
         return out
+
+    # ---- scan preprocessing (src/dlo/odom.cc:443-465) and map voxel filter (§8f-4; src/dlo/map.cc:100-131) ----
+    @staticmethod
+    def _intensity_offset(c: np.ndarray, intensity_col) -> int:
+        return -1 if intensity_col is None or intensity_col < 0 else int(intensity_col) * 4
+
+    def preprocessScan(self, cloud, remove_nan: bool = True, crop_size: float = 0.0, voxel_res: float = 0.0, intensity_col=None,
+                       set_as_source: bool = False) -> np.ndarray:
+        """removeNaN -> CropBox(negative, +-crop_size) -> VoxelGrid(voxel_res); returns (M, 4) {x, y, z, intensity}.  With
+        set_as_source the filtered cloud (still on the device) also becomes the source: setInputSource without an upload."""
+        c = np.asarray(cloud, dtype=np.float32)
+        if c.ndim != 2 or c.shape[1] < 3 or not c.flags.c_contiguous:
+            c = np.ascontiguousarray(c, dtype=np.float32)
+        out = np.empty((c.shape[0], 4), dtype=np.float32)
+        m = C.c_size_t(0)
+        self._ck(self._L.ngicp_preprocess_scan(self._h, _p(c, c_f32p), c.shape[0], c.strides[0], self._intensity_offset(c, intensity_col),
+                                               1 if remove_nan else 0, float(crop_size), float(voxel_res), _p(out, c_f32p), out.shape[0], C.byref(m)))
+        out = out[:m.value].copy()
+        if set_as_source:
+            self._ck(self._L.ngicp_set_source_preprocessed(self._h, 0))
+            self._src = np.ascontiguousarray(out[:, :3])
+        return out
+
+    def mapAdd(self, cloud, intensity_col=None):
+        c = np.asarray(cloud, dtype=np.float32)
+        if c.ndim != 2 or c.shape[1] < 3 or not c.flags.c_contiguous:
+            c = np.ascontiguousarray(c, dtype=np.float32)
+        self._ck(self._L.ngicp_map_add(self._h, _p(c, c_f32p), c.shape[0], c.strides[0], self._intensity_offset(c, intensity_col)))
+
+    def mapVoxelFilter(self, leaf: float) -> int:
+        m = C.c_size_t(0)
+        self._ck(self._L.ngicp_map_voxel_filter(self._h, float(leaf), C.byref(m)))
+        return m.value
+
+    def mapSize(self) -> int: return self._covs_size("ngicp_map_size")
+
+    def mapGet(self) -> np.ndarray:
+        n = self.mapSize()
+        out = np.empty((n, 4), dtype=np.float32)
+        if n:
+            self._ck(self._L.ngicp_map_get(self._h, _p(out, c_f32p), n))
+        return out
+
+    def mapClear(self): self._ck(self._L.ngicp_map_clear(self._h))
 
     def measureCopyBandwidth(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
         """Device float4 stream copy, (read + write) GB/s."""

@@ -277,6 +277,44 @@ class NanoGICP {
     }
     return changed != 0;
   }
+  // dlo::OdomNode::preprocessPoints (odom.cc:443-465): removeNaN -> CropBox(negative, +-crop_size) -> VoxelGrid(voxel_res), each
+  // optional (crop_size / voxel_res <= 0: off), on the GPU; `cloud` is replaced by the filtered cloud (x, y, z, intensity;
+  // data[3] = 1).  With set_as_source the filtered cloud, still on the device, also becomes this instance's input source.
+  void preprocessPoints(PointCloudSource& cloud, bool remove_nan, float crop_size, float voxel_res, bool set_as_source = false) {
+    if (!h_ || cloud.empty()) return;
+    std::vector<float> out(cloud.size() * 4);
+    size_t m = 0;
+    const long ioff = (long)((const char*)&cloud.points[0].intensity - (const char*)cloud.points[0].data);
+    if (!check(ngicp_preprocess_scan(h_, cloud.points[0].data, cloud.size(), sizeof(PointSource), ioff, remove_nan ? 1 : 0, crop_size, voxel_res, out.data(),
+                                     cloud.size(), &m), "preprocessPoints"))
+      return;
+    cloud.resize(m);
+    for (size_t i = 0; i < m; ++i) {
+      PointSource& p = cloud.points[i];
+      p.data[0] = out[i * 4 + 0]; p.data[1] = out[i * 4 + 1]; p.data[2] = out[i * 4 + 2]; p.data[3] = 1.0f;
+      p.intensity = out[i * 4 + 3];
+    }
+    if (set_as_source) check(ngicp_set_source_preprocessed(h_, 0), "set_source_preprocessed");
+  }
+  // dlo::MapNode (map.cc:100-131): `*dlo_map += *keyframe` and `voxelgrid.filter(*dlo_map)` on a device-resident map
+  void mapAdd(const PointCloudSource& keyframe) {
+    if (!h_ || keyframe.empty()) return;
+    const long ioff = (long)((const char*)&keyframe.points[0].intensity - (const char*)keyframe.points[0].data);
+    check(ngicp_map_add(h_, keyframe.points[0].data, keyframe.size(), sizeof(PointSource), ioff), "mapAdd");
+  }
+  size_t mapVoxelFilter(float leaf) { size_t m = 0; check(ngicp_map_voxel_filter(h_, leaf, &m), "mapVoxelFilter"); return m; }
+  void mapGet(PointCloudSource& out) {
+    size_t n = 0;
+    ngicp_map_size(h_, &n);
+    std::vector<float> buf(n * 4);
+    if (n && !check(ngicp_map_get(h_, buf.data(), n), "mapGet")) return;
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      PointSource& p = out.points[i];
+      p.data[0] = buf[i * 4 + 0]; p.data[1] = buf[i * 4 + 1]; p.data[2] = buf[i * 4 + 2]; p.data[3] = 1.0f;
+      p.intensity = buf[i * 4 + 3];
+    }
+  }
   // pcl::transformPointCloud(*getInputSource(), out, T) computed from the device-resident source (odom.cc:971-974)
   void transformSource(PointCloudSource& out, const Matrix4& T) {
     if (!h_ || !input_) return;

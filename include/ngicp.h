@@ -217,6 +217,31 @@ int ngicp_get_target_points(ngicp_t* h, float* xyz_out_or_null, size_t out_strid
 int ngicp_transform_source(ngicp_t* h, const float T_colmajor[16], float* xyz_out, size_t out_stride_bytes);
 int ngicp_transform_cloud(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes, const float T_colmajor[16], float* xyz_out, size_t out_stride_bytes);
 
+/* --- scan preprocessing ---------------------------------------------- */
+/* dlo::OdomNode::preprocessPoints (src/dlo/odom.cc:443-465, configured at :122-127): pcl::removeNaNFromPointCloud, then
+ * pcl::CropBox with setNegative(true) and min/max = -/+crop_half_extent (drops the points inside the cube around the
+ * sensor), then pcl::VoxelGrid with a cubic leaf (one centroid of x, y, z AND intensity per occupied voxel, in ascending
+ * voxel index).  Each stage is optional (remove_nan = 0, crop_half_extent <= 0, voxel_leaf <= 0).  Input: strided points,
+ * xyz at byte 0 and (optionally) a float intensity at intensity_offset_bytes (16 for pcl::PointXYZI; -1: none).  Output:
+ * 16 bytes per point {x, y, z, intensity}, written to out_xyzi (capacity in points; may be NULL) and kept on the device.
+ * PCL's sources are not under /root/reference: the rules are restated from memory (see csrc/ngicp_filters.hip).
+ * ngicp_set_source_preprocessed makes the filtered cloud (still on the device) the handle's source: setInputSource
+ * (odom.cc:519) without the download / upload pair. */
+int ngicp_preprocess_scan(ngicp_t* h, const float* pts, size_t n, size_t stride_bytes, long intensity_offset_bytes, int remove_nan, float crop_half_extent,
+                          float voxel_leaf, float* out_xyzi_or_null, size_t out_capacity, size_t* n_out);
+int ngicp_set_source_preprocessed(ngicp_t* h, uint64_t host_identity);
+
+/* --- map accumulation + voxel filter ---------------------------------- */
+/* dlo::MapNode (src/dlo/map.cc:100-131): `*dlo_map += *keyframe` per keyframe (ngicp_map_add: the keyframe is appended to
+ * a device-resident map), and on the publish timer `voxelgrid.filter(*dlo_map)` with a cubic leaf (ngicp_map_voxel_filter:
+ * the map is replaced by its voxel centroids, same rules as above); ngicp_map_get downloads it for publishing
+ * ({x, y, z, intensity}, 16 bytes per point). */
+int ngicp_map_add(ngicp_t* h, const float* pts, size_t n, size_t stride_bytes, long intensity_offset_bytes);
+int ngicp_map_voxel_filter(ngicp_t* h, float leaf, size_t* n_out_or_null);
+int ngicp_map_size(const ngicp_t* h, size_t* n);
+int ngicp_map_get(ngicp_t* h, float* out_xyzi, size_t out_capacity);
+int ngicp_map_clear(ngicp_t* h);
+
 /* --- measurement: device stream copy -------------------------------- */
 /* float4 grid-stride copy of `bytes` bytes, `reps` times on the handle's stream, HIP-event timed: (read + write) GB/s. */
 int ngicp_measure_copy_bandwidth(ngicp_t* h, size_t bytes, int reps, double* gbps_out);

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <utility>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -1088,6 +1089,76 @@ int orc_gicp_get_trace(const orc_gicp* g, double* out) {
   return 0;
 }
 double orc_gicp_lambda(const orc_gicp* g) { return g->lm_lambda; }
+
+// ----------------------------------------------------------------------------
+// "filters": pcl::removeNaNFromPointCloud, pcl::CropBox (negative) and pcl::VoxelGrid as DLO uses them
+// (/root/reference/src/dlo/odom.cc:443-465 with :122-127; src/dlo/map.cc:100-131).  PCL is NOT under /root/reference
+// (PCL >= 1.10, unpinned: README.md:27) and not installed here: restated FROM MEMORY of pcl/filters/filter.hpp,
+// pcl/filters/impl/crop_box.hpp and pcl/filters/impl/voxel_grid.hpp -> parity unpinned.
+//   in : n strided points (xyz at float 0..2, intensity at float `ioff`, or ioff < 0: none)
+//   out: packed {x, y, z, intensity} (4 floats per point), returns the number of points written
+// VoxelGrid: inverse_leaf = 1 / leaf (float); bounding box of the input -> min_b = floor(min * inv), div_b = max_b - min_b + 1;
+// voxel index (i - min_b.x) + (j - min_b.y) div.x + (k - min_b.z) div.x div.y; points sorted by index; per voxel the
+// centroid of all fields = float sums / count (pcl::CentroidPoint), output in ascending index.  PCL's std::sort leaves the
+// order inside a voxel unspecified; here the sort is stable (input order), which only affects the last bits of the sums.
+// If the index would overflow int32 PCL warns and returns the input unchanged.
+// ----------------------------------------------------------------------------
+size_t orc_filter_cloud(const float* pts, size_t n, size_t stride_floats, long ioff, int remove_nan, float crop_half, float leaf, float* out_xyzi) {
+  std::vector<float> cur;  // packed survivors
+  cur.reserve(n * 4);
+  const bool voxel = leaf > 0.f;
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = pts + i * stride_floats;
+    const float x = p[0], y = p[1], z = p[2], it = ioff >= 0 ? p[ioff] : 0.f;
+    if ((remove_nan || voxel) && !(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) continue;
+    if (crop_half > 0.f && !(x < -crop_half || y < -crop_half || z < -crop_half || x > crop_half || y > crop_half || z > crop_half)) continue;
+    cur.push_back(x); cur.push_back(y); cur.push_back(z); cur.push_back(it);
+  }
+  size_t m = cur.size() / 4;
+  if (!voxel || m == 0) {
+    std::memcpy(out_xyzi, cur.data(), cur.size() * sizeof(float));
+    return m;
+  }
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (size_t i = 0; i < m; ++i)
+    for (int d = 0; d < 3; ++d) {
+      mn[d] = std::min(mn[d], cur[i * 4 + d]);
+      mx[d] = std::max(mx[d], cur[i * 4 + d]);
+    }
+  const float inv = 1.0f / leaf;
+  int min_b[3], div[3];
+  long long cells = 1;
+  for (int d = 0; d < 3; ++d) {
+    min_b[d] = (int)std::floor(mn[d] * inv);
+    div[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+    cells *= (long long)div[d];
+    if (cells > (long long)std::numeric_limits<int>::max()) {  // "Leaf size is too small for the input dataset": output = input
+      std::memcpy(out_xyzi, cur.data(), cur.size() * sizeof(float));
+      return m;
+    }
+  }
+  std::vector<std::pair<unsigned int, unsigned int>> idx(m);
+  for (size_t i = 0; i < m; ++i) {
+    const int a = (int)std::floor(cur[i * 4 + 0] * inv) - min_b[0], b = (int)std::floor(cur[i * 4 + 1] * inv) - min_b[1], c = (int)std::floor(cur[i * 4 + 2] * inv) - min_b[2];
+    idx[i] = {(unsigned int)(a + b * div[0] + c * div[0] * div[1]), (unsigned int)i};
+  }
+  std::stable_sort(idx.begin(), idx.end(), [](const std::pair<unsigned int, unsigned int>& l, const std::pair<unsigned int, unsigned int>& r) { return l.first < r.first; });
+  size_t nv = 0;
+  for (size_t s0 = 0; s0 < m;) {
+    size_t e0 = s0;
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    while (e0 < m && idx[e0].first == idx[s0].first) {
+      const float* p = &cur[(size_t)idx[e0].second * 4];
+      sx += p[0]; sy += p[1]; sz += p[2]; si += p[3];
+      ++e0;
+    }
+    const float cnt = (float)(e0 - s0);
+    out_xyzi[nv * 4 + 0] = sx / cnt; out_xyzi[nv * 4 + 1] = sy / cnt; out_xyzi[nv * 4 + 2] = sz / cnt; out_xyzi[nv * 4 + 3] = si / cnt;
+    ++nv;
+    s0 = e0;
+  }
+  return nv;
+}
 
 // pcl::transformPointCloud restated (see transform_point_pcl): strided xyz in, packed xyz out
 int orc_transform_cloud(const float* xyz, size_t n, size_t stride_floats, const float T_colmajor[16], int sse_order, float* out_xyz) {

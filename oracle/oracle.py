@@ -78,6 +78,8 @@ def lib() -> C.CDLL:
         L.orc_gicp_lambda.restype = C.c_double
         L.orc_gicp_set_debug.argtypes = [C.c_void_p, C.c_int]
         L.orc_transform_cloud.argtypes = [c_f32p, C.c_size_t, C.c_size_t, c_f32p, C.c_int, c_f32p]
+        L.orc_filter_cloud.argtypes = [c_f32p, C.c_size_t, C.c_size_t, C.c_long, C.c_int, C.c_float, C.c_float, c_f32p]
+        L.orc_filter_cloud.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -153,6 +155,14 @@ def transform_cloud(pts, T, sse_order: bool = True) -> np.ndarray:
     out = np.empty((pts.shape[0], 3), dtype=np.float32)
     lib().orc_transform_cloud(_fp(pts, c_f32p), pts.shape[0], pts.shape[1], _fp(t, c_f32p), 1 if sse_order else 0, _fp(out, c_f32p))
     return out
+
+
+def filter_cloud(pts, remove_nan: bool = True, crop_half: float = 0.0, leaf: float = 0.0, intensity_col: int = -1) -> np.ndarray:
+    """removeNaN + CropBox(negative) + VoxelGrid restated (ngicp_oracle.cpp "filters"; parity unpinned): (M, 4) {x, y, z, intensity}."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty((pts.shape[0], 4), dtype=np.float32)
+    m = lib().orc_filter_cloud(_fp(pts, c_f32p), pts.shape[0], pts.shape[1], intensity_col, 1 if remove_nan else 0, crop_half, leaf, _fp(out, c_f32p))
+    return out[:m].copy()
 
 
 def so3_exp(w) -> np.ndarray:

@@ -148,3 +148,74 @@ def test_copy_bandwidth_is_measured(ng):
     g = ng.NanoGICP()
     bw = g.measureCopyBandwidth(1 << 28, 5)
     assert 500.0 < bw < 9000.0, bw  # GB/s, read + write; MI355X nominal 8 TB/s, ~6 TB/s achievable
+
+
+# ------------------------------------------------------------------ f2: scan preprocessing, f4: map voxel filter
+def _raw_scan(n=60_000, seed=7):
+    """A scan as the driver delivers it: x y z intensity, with NaN returns and points on the robot itself."""
+    rng = np.random.default_rng(seed)
+    w = clouds.scan_to_scan(10_000)
+    pts = np.concatenate([w.source] * (n // len(w.source) + 1))[:n] + rng.normal(0, 0.02, (n, 3)).astype(np.float32)
+    cloud = np.zeros((n, 8), np.float32)  # 32-byte pcl::PointXYZI layout: x y z 1 | intensity 0 0 0
+    cloud[:, :3] = pts; cloud[:, 3] = 1.0; cloud[:, 4] = rng.uniform(0, 255, n).astype(np.float32)
+    cloud[rng.choice(n, 500, replace=False), rng.integers(0, 3, 500)] = np.nan           # invalid returns
+    cloud[rng.choice(n, 300, replace=False), :3] = rng.uniform(-0.9, 0.9, (300, 3)).astype(np.float32)  # hits on the robot (inside the crop box)
+    return cloud
+
+
+@pytest.mark.parametrize("stages", [dict(remove_nan=True), dict(remove_nan=True, crop=1.0), dict(remove_nan=True, crop=1.0, leaf=0.25),
+                                    dict(remove_nan=False, leaf=0.5), dict(remove_nan=True, leaf=0.05)])
+def test_preprocess_scan_matches_oracle_restatement(ng, oracle_mod, stages):
+    """dlo::OdomNode::preprocessPoints (odom.cc:443-465; cfg/params.yaml:26-36: crop 1.0 m, scan voxel 0.25 m) against the oracle's
+    restatement of removeNaN / CropBox / VoxelGrid (PCL's source is not under /root/reference: parity unpinned) - bit for bit:
+    same survivors in the same order, same voxels in ascending index, centroids (x, y, z AND intensity) summed in input order."""
+    cloud = _raw_scan()
+    g = ng.NanoGICP()
+    got = g.preprocessScan(cloud, remove_nan=stages.get("remove_nan", True), crop_size=stages.get("crop", 0.0), voxel_res=stages.get("leaf", 0.0), intensity_col=4)
+    ref = oracle_mod.filter_cloud(cloud, stages.get("remove_nan", True), stages.get("crop", 0.0), stages.get("leaf", 0.0), intensity_col=4)
+    assert got.shape == ref.shape and got.shape[0] > 100
+    assert np.array_equal(got, ref)
+    assert np.isfinite(got[:, :3]).all()
+    if stages.get("crop") and not stages.get("leaf"):
+        assert not (np.abs(got[:, :3]) <= stages["crop"]).all(axis=1).any()  # nothing left inside the box
+    if stages.get("leaf"):  # one output point per occupied voxel of the survivors
+        surv = oracle_mod.filter_cloud(cloud, stages.get("remove_nan", True), stages.get("crop", 0.0), 0.0, intensity_col=4)
+        surv = surv[np.isfinite(surv[:, :3]).all(axis=1)]
+        keys = np.floor(surv[:, :3] * np.float32(1.0 / stages["leaf"])).astype(np.int64)
+        assert len(np.unique(keys, axis=0)) == len(got)
+
+
+def test_preprocessed_scan_becomes_the_source_without_a_round_trip(ng, oracle_mod):
+    """preprocessPoints followed by setInputSource(current_scan) (odom.cc:443-465, 519): the filtered cloud, still on the device,
+    is indexed directly; aligning it must equal aligning the downloaded copy set the ordinary way."""
+    cloud = _raw_scan()
+    w = clouds.scan_to_scan(10_000)
+    a, b = ng.NanoGICP(), ng.NanoGICP()
+    for e in (a, b):
+        e.setMaxCorrespondenceDistance(1.0); e.setInputTarget(w.target)
+    filtered = a.preprocessScan(cloud, True, 1.0, 0.25, intensity_col=4, set_as_source=True)
+    b.setInputSource(np.ascontiguousarray(filtered[:, :3]))
+    a.align(); b.align()
+    assert np.array_equal(a.getFinalTransformation(), b.getFinalTransformation()) and a.nr_iterations_ == b.nr_iterations_
+    assert np.array_equal(a.getSourceCovariances(), b.getSourceCovariances())
+
+
+def test_map_accumulation_and_voxel_filter(ng, oracle_mod):
+    """dlo::MapNode (map.cc:100-131): keyframes appended to the map, the whole map voxel-filtered on every publish."""
+    w = clouds.scan_to_submap(6_000, 4)
+    kfs = np.split(w.target, np.cumsum(w.keyframe_sizes)[:-1])
+    rng = np.random.default_rng(3)
+    g = ng.NanoGICP()
+    host = np.zeros((0, 4), np.float32)
+    for i, kf in enumerate(kfs):
+        kfi = np.c_[kf, rng.uniform(0, 100, len(kf)).astype(np.float32)]
+        g.mapAdd(kfi, intensity_col=3)
+        host = np.concatenate([host, kfi])
+        assert g.mapSize() == len(host)
+        if i % 2 == 1:  # a publish tick: voxelgrid.filter(*dlo_map) replaces the map
+            m = g.mapVoxelFilter(0.3)
+            host = oracle_mod.filter_cloud(host, False, 0.0, 0.3, intensity_col=3)
+            assert m == len(host)
+            assert np.array_equal(g.mapGet(), host)
+    g.mapClear()
+    assert g.mapSize() == 0 and g.mapGet().shape == (0, 4)
