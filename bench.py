@@ -22,6 +22,7 @@ fails, AFTER printing the line) and, at N == 1, extra keys measured in the same 
                      kernel's roofline numbers on the configuration where the working set exceeds L2
   hbm_copy_measured_GBps   a float4 device stream copy on this box, next to the nominal 8 TB/s
   submap             SURVEY.md §8f-1: device-resident keyframe store vs the reference's host route
+  preprocess         SURVEY.md §8f-2: removeNaN + CropBox + VoxelGrid of a raw 100k-point scan
   dlo_frame          one LiDAR frame with DLO's own settings
 """
 from __future__ import annotations
@@ -143,6 +144,23 @@ def submap_routes_ms(ng, w, device, reps=3):
             "device_route": "ngicp_submap_set: device concat of the keyframes' points + covariances, one index build, no host traffic"}
 
 
+def preprocess_ms(ng, w, device, reps=4):
+    """SURVEY.md §8f-2: dlo::OdomNode::preprocessPoints with DLO's settings (cfg/params.yaml:26-36: crop 1.0 m, voxel 0.25 m) on a
+    raw 100k-point scan in the 32-byte pcl::PointXYZI layout: upload, removeNaN + CropBox + VoxelGrid, download."""
+    from direct_lidar_odometry_amd import clouds
+    g = ng.NanoGICP(device=device)
+    raw = clouds.to_xyzi(w.source)
+    raw[::97, 1] = np.nan
+    t = []
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        out = g.preprocessScan(raw, True, 1.0, 0.25, intensity_col=4)
+        t.append((time.perf_counter() - t0) * 1e3)
+    g.close()
+    return {"median_ms": statistics.median(t[1:]), "points_in": int(len(raw)), "points_out": int(len(out)),
+            "stages": "removeNaN + CropBox(negative, 1.0 m) + VoxelGrid(0.25 m), host PointXYZI in -> host {x,y,z,intensity} out"}
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -226,9 +244,11 @@ def roofline_block(n_src, cbar, passes_per_align, avg_pass_ms):
     return bytes_per_launch, achieved, floor
 
 
-def committed_traffic(name):
+def committed_traffic(cfg):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (separate runs; NOT measured in this run)."""
-    for fn in (f"r02_{name}_hbm_traffic.json", f"r01_{name}_hbm_traffic.json"):
+    for fn in (f"r02_{cfg}_pass_counters.json", "r01_pass_hbm_traffic.json" if cfg == "c3" else ""):
+        if not fn:
+            continue
         p = os.path.join(ROOT, "profiles", fn)
         if os.path.exists(p):
             try:
@@ -269,7 +289,7 @@ def c5_leg(ng, device, aligns=5, warmup=2):
     cbar = cand / aligns
     avg = pass_ms / max(1, passes_timed)
     nbytes, achieved, floor = roofline_block(s["n_src"], cbar, s["passes"], avg)
-    traffic, src = committed_traffic("c5_pass")
+    traffic, src = committed_traffic("c5")
     out = {"workload": "scan_to_submap_250k_vs_2M_os1 (BASELINE configs[4])", "ms_per_align": elapsed * 1e3 / aligns, "iterations_per_s": iters / elapsed,
            "passes": s["passes"], "mean_candidates_per_query": cbar, "valid_fraction": s["valid_fraction"], "avg_launch_ms": avg, "launches_timed": passes_timed,
            "algorithmic_bytes_per_launch": nbytes, "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS, "floor_frac_cbar1": floor,
@@ -365,7 +385,7 @@ def main():
         cbar = cand / max(1, args.steps * s["passes"])
         avg_pass_ms = pass_ms / max(1, passes)
         bytes_per_launch, achieved, floor = roofline_block(n_src, cbar, s["passes"], avg_pass_ms)
-        traffic, traffic_src = committed_traffic("pass")
+        traffic, traffic_src = committed_traffic("c3")
         out = {
             "metric": "gicp_iterations_per_sec",
             "value": total_iters / elapsed,
@@ -403,7 +423,8 @@ def main():
                 out["hbm_copy_measured_GBps"] = {"error": str(exc)}
         if world == 1 and not args.no_extras:
             for key, fn in (("ms_per_scan_detail", lambda: ms_per_scan_gpu(g, w)), ("dlo_frame", lambda: dlo_frame_ms(ng, w, tgt_covs, local_rank)),
-                            ("submap", lambda: submap_routes_ms(ng, w, local_rank)), ("c5", lambda: c5_leg(ng, local_rank))):
+                            ("submap", lambda: submap_routes_ms(ng, w, local_rank)), ("preprocess", lambda: preprocess_ms(ng, w, local_rank)),
+                            ("c5", lambda: c5_leg(ng, local_rank))):
                 try:
                     out[key] = fn()
                 except Exception as exc:  # informative extras, never fatal

@@ -1650,6 +1650,23 @@ int ngicp_transform_cloud(ngicp_t* h, const float* xyz, size_t n, size_t stride_
   });
 }
 
+// ---- test hook: ngicp_math.h on the device ----
+int ngicp_math_selftest(ngicp_t* h, int which, const double* in, size_t n_problems, double* out) {
+  return guarded(h, [&] {
+    static const int kIn[4] = {3, 42, 6, 6}, kOut[4] = {9, 6, 12, 6};
+    if (which < 0 || which > 3 || !in || !out) throw ArgError{NGICP_ERR_ARG, "bad arguments"};
+    if (n_problems == 0) return;
+    DevBuf di, dout;
+    di.ensure(n_problems * kIn[which] * sizeof(double));
+    dout.ensure(n_problems * kOut[which] * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(di.p, in, n_problems * kIn[which] * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_math_selftest, dim3((unsigned)((n_problems + 63) / 64)), dim3(64), 0, h->stream, which, di.as<double>(), (int)n_problems, dout.as<double>());
+    HIP_TRY(hipMemcpyAsync(out, dout.p, n_problems * kOut[which] * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+  });
+}
+
 // ---- measurement: device stream copy ----
 int ngicp_measure_copy_bandwidth(ngicp_t* h, size_t bytes, int reps, double* gbps_out) {
   return guarded(h, [&] {

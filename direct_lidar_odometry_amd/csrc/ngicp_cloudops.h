@@ -5,6 +5,7 @@
 //   rigid transform      pcl::transformPointCloud with a float matrix: impl/lsq_registration_impl.hpp:114, odom.cc:484,971-974
 #pragma once
 #include "ngicp_grid.h"
+#include "ngicp_math.h"
 
 namespace ngk {
 
@@ -150,6 +151,40 @@ __global__ void __launch_bounds__(256) k_xyzi_to_unsorted(const float4* __restri
     float v = lds[0][d];
     for (int w = 1; w < 4; ++w) v = d < 3 ? fminf(v, lds[w][d]) : fmaxf(v, lds[w][d]);
     bbox_part[blockIdx.x * 8 + d] = v;
+  }
+}
+
+// Test hook: the small FP64 routines of ngicp_math.h evaluated ON THE DEVICE, one problem per thread (they are otherwise only
+// reachable through whole alignments: so3_exp's Taylor branch, for one, only when a step happens to be < 1e-5 rad).
+//   which 0: so3_exp_matrix   in 3  -> out 9      (gicp/so3.hpp:99-118 + Quaternion::toRotationMatrix)
+//         1: ldlt6_solve      in 42 -> out 6      (A row-major 36, rhs 6; impl/lsq_registration_impl.hpp:147-148,172-173)
+//         2: eig3_sym         in 6  -> out 12     (w 3, V 9; stands in for JacobiSVD, impl/nano_gicp_impl.hpp:332)
+//         3: inv3_sym         in 6  -> out 6      (impl/nano_gicp_impl.hpp:205-209)
+__global__ void __launch_bounds__(64) k_math_selftest(int which, const double* __restrict__ in, int n_problems, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_problems) return;
+  if (which == 0) {
+    double w[3], R[9];
+    for (int e = 0; e < 3; ++e) w[e] = in[i * 3 + e];
+    so3_exp_matrix(w, R);
+    for (int e = 0; e < 9; ++e) out[i * 9 + e] = R[e];
+  } else if (which == 1) {
+    double A[36], rhs[6], x[6];
+    for (int e = 0; e < 36; ++e) A[e] = in[i * 42 + e];
+    for (int e = 0; e < 6; ++e) rhs[e] = in[i * 42 + 36 + e];
+    ldlt6_solve(A, rhs, x);
+    for (int e = 0; e < 6; ++e) out[i * 6 + e] = x[e];
+  } else if (which == 2) {
+    double C[6], w[3], V[9];
+    for (int e = 0; e < 6; ++e) C[e] = in[i * 6 + e];
+    eig3_sym(C, w, V);
+    for (int e = 0; e < 3; ++e) out[i * 12 + e] = w[e];
+    for (int e = 0; e < 9; ++e) out[i * 12 + 3 + e] = V[e];
+  } else {
+    double C[6], M[6];
+    for (int e = 0; e < 6; ++e) C[e] = in[i * 6 + e];
+    inv3_sym(C, M);
+    for (int e = 0; e < 6; ++e) out[i * 6 + e] = M[e];
   }
 }
 

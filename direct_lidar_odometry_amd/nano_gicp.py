@@ -72,7 +72,7 @@ EXPORTS = [
     "ngicp_keyframe_add", "ngicp_keyframe_add_transformed", "ngicp_keyframe_count", "ngicp_keyframe_size", "ngicp_keyframe_clear",
     "ngicp_submap_set", "ngicp_get_target_points", "ngicp_transform_source", "ngicp_transform_cloud", "ngicp_measure_copy_bandwidth",
     "ngicp_preprocess_scan", "ngicp_set_source_preprocessed", "ngicp_map_add", "ngicp_map_voxel_filter", "ngicp_map_size", "ngicp_map_get",
-    "ngicp_map_clear",
+    "ngicp_map_clear", "ngicp_math_selftest",
 ]
 
 _lib = None
@@ -140,6 +140,7 @@ def load_library() -> C.CDLL:
     L.ngicp_map_size.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.ngicp_map_get.argtypes = [vp, c_f32p, C.c_size_t]
     L.ngicp_map_clear.argtypes = [vp]
+    L.ngicp_math_selftest.argtypes = [vp, C.c_int, c_f64p, C.c_size_t, c_f64p]
     _lib = L
     return L
 
@@ -459,6 +460,13 @@ class NanoGICP:
         return out
 
     def mapClear(self): self._ck(self._L.ngicp_map_clear(self._h))
+
+    def mathSelftest(self, which: int, problems) -> np.ndarray:
+        """ngicp_math.h on the device (0 so3_exp, 1 ldlt6_solve, 2 eig3_sym, 3 inv3_sym), one problem per row."""
+        a = np.ascontiguousarray(problems, dtype=np.float64)
+        out = np.empty((a.shape[0], (9, 6, 12, 6)[which]))
+        self._ck(self._L.ngicp_math_selftest(self._h, int(which), _p(a, c_f64p), a.shape[0], _p(out, c_f64p)))
+        return out
 
     def measureCopyBandwidth(self, nbytes: int = 1 << 30, reps: int = 10) -> float:
         """Device float4 stream copy, (read + write) GB/s."""

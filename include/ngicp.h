@@ -140,6 +140,13 @@ int ngicp_target_knn(ngicp_t* h, const float* queries_xyz, size_t nq, size_t str
  * (the columns setDebugPrint prints, impl/lsq_registration_impl.hpp:183-189). */
 int ngicp_get_lm_trace(ngicp_t* h, double* rows8_or_null, size_t max_rows, size_t* n_rows);
 
+/* The small FP64 routines of the engine evaluated on the device, one problem per thread (unit-test hook): which = 0 so3_exp
+ * (gicp/so3.hpp:99-118 followed by Quaternion::toRotationMatrix; in: 3 doubles, out: R row-major 9), 1 the 6x6 LDLT solve that
+ * stands in for Eigen::LDLT (impl/lsq_registration_impl.hpp:147-148,172-173; in: A row-major 36 + rhs 6, out: 6), 2 the
+ * symmetric 3x3 eigen-decomposition that stands in for JacobiSVD (impl/nano_gicp_impl.hpp:332; in: {xx,xy,xz,yy,yz,zz}, out:
+ * w 3 + V row-major 9), 3 the symmetric 3x3 inverse (impl/nano_gicp_impl.hpp:205-209; in 6, out 6). */
+int ngicp_math_selftest(ngicp_t* h, int which, const double* in, size_t n_problems, double* out);
+
 /* --- measurement ----------------------------------------------------------- */
 typedef struct ngicp_stats {
   double align_ms;          /* host wall time of the last ngicp_align() */

@@ -454,3 +454,54 @@ def test_full_size_properties(ng):
         assert np.allclose(tr[:3, [2, 3]], runs[0][1][:3, [2, 3]], rtol=1e-9) and np.allclose(tr[:, [2, 3]], runs[0][1][:, [2, 3]], rtol=1e-4)
         assert np.allclose(tr[:, [5, 6]], runs[0][1][:, [5, 6]], rtol=1e-2)
         assert np.allclose(tr[:, 4], runs[0][1][:, 4], atol=1e-2)
+
+
+# ------------------------------------------------------------------ the small FP64 routines, directly on the device
+def test_device_math_matches_oracle(ng, oracle_mod):
+    """so3_exp (both branches: the Taylor series for theta^2 < 1e-10 and the sin / cos form, gicp/so3.hpp:99-118), the 6x6 LDLT
+    solve, the symmetric 3x3 eigen-decomposition and inverse, evaluated by the HIP build of csrc/ngicp_math.h and compared with
+    the oracle's own restatements (and with numpy where a closed form exists)."""
+    g = ng.NanoGICP()
+    rng = np.random.default_rng(11)
+    # so3_exp: tiny rotations (Taylor branch), the branch boundary, ordinary and large rotations
+    w = np.concatenate([rng.normal(size=(50, 3)) * 1e-7, rng.normal(size=(50, 3)) * 3e-6, np.array([[1e-5, 0, 0], [0, 1.0000001e-5, 0], [0, 0, 0]]),
+                        rng.normal(size=(100, 3)) * 0.01, rng.normal(size=(100, 3)), rng.normal(size=(20, 3)) * 3.0])
+    R = g.mathSelftest(0, w).reshape(-1, 3, 3)
+    Ro = np.stack([oracle_mod.so3_exp(x) for x in w])
+    assert np.abs(R - Ro).max() <= 4e-16  # same formula, same order: a rounding apart at most (device libm sin / cos)
+    assert (np.sum(w ** 2, axis=1) < 1e-10).sum() >= 50 and (np.sum(w ** 2, axis=1) >= 1e-10).sum() >= 100  # both branches exercised
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-14
+    # 6x6 LDLT: well-conditioned SPD, GICP-like (badly scaled) and a semi-definite one with a zero pivot
+    A = []
+    for i in range(60):
+        m = rng.normal(size=(6, 6)); a = m @ m.T + (1e-3 if i % 3 else 1e3) * np.eye(6)
+        if i % 3 == 2:
+            s = np.diag([1e6, 1e6, 1e6, 1.0, 1.0, 1.0]); a = s @ a @ s
+        A.append(a)
+    semi = np.diag([2.0, 0.0, 3.0, 1.0, 5.0, 4.0]); A.append(semi)
+    A = np.stack(A); rhs = rng.normal(size=(len(A), 6))
+    x = g.mathSelftest(1, np.concatenate([A.reshape(len(A), 36), rhs], axis=1))
+    xo = np.stack([oracle_mod.ldlt6_solve(a, r) for a, r in zip(A, rhs)])
+    assert np.allclose(x, xo, rtol=1e-9, atol=1e-12)
+    assert np.allclose(np.einsum("nij,nj->ni", A[:-1], x[:-1]), rhs[:-1], rtol=1e-6, atol=1e-6)
+    assert x[-1, 1] == 0.0  # a zero pivot contributes zero, like Eigen's LDLT::solve
+    # symmetric 3x3: covariance-like matrices incl. nearly planar / nearly linear ones
+    C = []
+    for i in range(200):
+        p = rng.normal(size=(20, 3)) * np.array([1.0, 10.0 ** -(i % 5), 10.0 ** -(i % 7)]); p -= p.mean(0); c = p.T @ p / 20
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3))); c = q @ c @ q.T
+        C.append([c[0, 0], c[0, 1], c[0, 2], c[1, 1], c[1, 2], c[2, 2]])
+    C = np.array(C)
+    ev = g.mathSelftest(2, C)
+    full = np.stack([[[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]] for c in C])
+    wv, V = ev[:, :3], ev[:, 3:].reshape(-1, 3, 3)
+    assert np.allclose(np.sort(wv, axis=1), np.linalg.eigvalsh(full), rtol=1e-9, atol=1e-15)
+    assert np.abs(np.einsum("nij,nj,nkj->nik", V, wv, V) - full).max() < 1e-12  # V diag(w) V^T reproduces the matrix
+    for c, (w3, V3) in zip(C[:40], zip(wv, V)):
+        wo, Vo = oracle_mod.eig3_sym(np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]]))
+        assert np.allclose(w3, wo, rtol=1e-12, atol=1e-18) and np.allclose(np.abs(V3), np.abs(Vo), atol=1e-9)
+    Ci = C.copy(); Ci[:, [0, 3, 5]] += 1e-3
+    inv = g.mathSelftest(3, Ci)
+    fulli = np.stack([[[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]] for c in Ci])
+    got = np.stack([[[m[0], m[1], m[2]], [m[1], m[3], m[4]], [m[2], m[4], m[5]]] for m in inv])
+    assert np.allclose(got, np.linalg.inv(fulli), rtol=1e-8, atol=0)
