@@ -943,34 +943,51 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ int ord_cnt[16], ord_pos[16], ord_max;
   __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
-  if (a.mode == 0 && st->hot.done) return;
 #define NG_SSTAMP(k)                                                                 \
   do {                                                                               \
     if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
   NG_SSTAMP(0);
-  // the state the serial lane will work on: fetched now by the whole block (one coalesced round trip that overlaps the
-  // partial loads) instead of by lane 0 after the reduction, where it would be a dependent round trip on the critical path
-  // The serial lane then works on this LDS image in place (a register-resident copy needs ~260 VGPRs: it spills at two waves
-  // per SIMD), and wave 0 stores it back with one coalesced pass.
-  __shared__ LmHot L;
-  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
-  for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) reinterpret_cast<int*>(&L)[w] = reinterpret_cast<const int*>(&st->hot)[w];
-  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
-  if (order_it)  // the groups' measured costs, for the launch order built further down (visible after the barriers below)
-    for (int gi = threadIdx.x; gi < a.nblocks; gi += kSolveThreads) ord_cost[gi] = a.grp_cost[gi];
-
   // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
   //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, 32 sixteen-byte loads in flight per step (one step
   //      covers 1024 groups: the whole c3 grid in a single memory round trip); the 32 subset sums of a slot are then added
-  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass. ----
+  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass.
+  //      The first step's loads are issued BEFORE anything else, so that the staging loads below (state image, group costs)
+  //      share their round trip instead of preceding it. ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
+  const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
+  double2 p[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const int gi = sb + j * kSolveSubs;
+    p[j] = gi < a.nblocks ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
+  }
+  if (a.mode == 0 && st->hot.done) return;  // (checked behind the loads above: its own round trip overlaps theirs)
+  // The state the serial lane will work on: fetched by the whole block (one coalesced round trip) instead of by lane 0 after
+  // the reduction, where it would be a dependent round trip on the critical path.  The serial lane then works on this LDS
+  // image in place (a register-resident copy needs ~260 VGPRs: it spills at two waves per SIMD), and wave 0 stores it back
+  // with one coalesced pass.
+  __shared__ LmHot L;
+  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
   {
-    const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
-    const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
+    int hv[(sizeof(LmHot) / 4 + kSolveThreads - 1) / kSolveThreads];
+    int k = 0;
+    for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) hv[k++] = reinterpret_cast<const int*>(&st->hot)[w];
+    k = 0;
+    for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) reinterpret_cast<int*>(&L)[w] = hv[k++];
+  }
+  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
+  if (order_it)  // the groups' measured costs, for the launch order built further down (visible after the barriers below)
+    for (int gi = threadIdx.x; gi < a.nblocks; gi += kSolveThreads) ord_cost[gi] = a.grp_cost[gi];
+  {
     double a0 = 0.0, a1 = 0.0;
-    for (int g0 = sb; g0 < a.nblocks; g0 += kSolveSubs * 32) {
-      double2 p[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      a0 += p[j].x;
+      a1 += p[j].y;
+    }
+    for (int g0 = sb + kSolveSubs * 32; g0 < a.nblocks; g0 += kSolveSubs * 32) {  // grids beyond 1024 groups: further steps
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
         const int gi = g0 + j * kSolveSubs;

@@ -468,7 +468,7 @@ def test_device_math_matches_oracle(ng, oracle_mod):
                         rng.normal(size=(100, 3)) * 0.01, rng.normal(size=(100, 3)), rng.normal(size=(20, 3)) * 3.0])
     R = g.mathSelftest(0, w).reshape(-1, 3, 3)
     Ro = np.stack([oracle_mod.so3_exp(x) for x in w])
-    assert np.abs(R - Ro).max() <= 4e-16  # same formula, same order: a rounding apart at most (device libm sin / cos)
+    assert np.abs(R - Ro).max() <= 2e-15  # same formula, same order: a few roundings apart at most (device libm sqrt / sin / cos)
     assert (np.sum(w ** 2, axis=1) < 1e-10).sum() >= 50 and (np.sum(w ** 2, axis=1) >= 1e-10).sum() >= 100  # both branches exercised
     assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-14
     # 6x6 LDLT: well-conditioned SPD, GICP-like (badly scaled) and a semi-definite one with a zero pivot
