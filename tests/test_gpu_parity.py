@@ -499,7 +499,10 @@ def test_device_math_matches_oracle(ng, oracle_mod):
     assert np.abs(np.einsum("nij,nj,nkj->nik", V, wv, V) - full).max() < 1e-12  # V diag(w) V^T reproduces the matrix
     for c, (w3, V3) in zip(C[:40], zip(wv, V)):
         wo, Vo = oracle_mod.eig3_sym(np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]]))
-        assert np.allclose(w3, wo, rtol=1e-12, atol=1e-18) and np.allclose(np.abs(V3), np.abs(Vo), atol=1e-9)
+        i3, io = np.argsort(-w3), np.argsort(-wo)  # (the two return their eigenpairs in different orders)
+        assert np.allclose(w3[i3], wo[io], rtol=1e-12, atol=1e-18)
+        if np.min(np.abs(np.diff(w3[i3]))) > 1e-6 * np.abs(w3).max():  # eigenvectors are only defined for separated eigenvalues
+            assert np.allclose(np.abs(V3[:, i3]), np.abs(Vo[:, io]), atol=1e-7)
     Ci = C.copy(); Ci[:, [0, 3, 5]] += 1e-3
     inv = g.mathSelftest(3, Ci)
     fulli = np.stack([[[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]] for c in Ci])
