@@ -143,30 +143,65 @@ __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, 
   }
 }
 
+constexpr int kKnnBlock = 128;  // threads per block of the k-NN kernels (each thread parks 36 row bounds in LDS)
+
 template <int K>
 __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                           int p, int k, TopK<K>& top) {
+                                           int p, int k, TopK<K>& top, int* __restrict__ lds_bounds /* [36][kKnnBlock], this thread's column */) {
   top.init();
   float worst = 3.4028234664e38f;
   int cx, cy, cz;
   cell_coords(g, qx, qy, qz, cx, cy, cz);
+  // ---- rings 0..1: the bounds of all nine rows of the 3 x 3 window are fetched in ONE round trip (one 16-byte load per row gives
+  //      the starts of the cells cx-1, cx, cx+1, cx+2: the cell-start table is padded for it); the query's own row is walked
+  //      first, from the query itself when it is a point of this cloud, else from where qx sits inside its own cell ----
+  {
+    struct alignas(4) Bounds4 { int v[4]; };
+    {
+      Bounds4 bnd[9];  // all nine loads in flight, then parked in LDS (indexed by a run-time row below: registers would spill)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int y = min(max(cy + t % 3 - 1, 0), g.ny - 1), z = min(max(cz + t / 3 - 1, 0), g.nz - 1);  // (rows outside the grid are skipped below)
+        bnd[t] = *reinterpret_cast<const Bounds4*>(cell_start + ((z * g.ny + y) * g.nx + cx - 1));
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) lds_bounds[(t * 4 + v) * kKnnBlock] = bnd[t].v[v];
+    }
+    const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
+    for (int o = 0; o < 9; ++o) {
+      const int t = o == 0 ? 4 : (o <= 4 ? o - 1 : o);  // the own row first
+      const int y = cy + t % 3 - 1, z = cz + t / 3 - 1;
+      if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+      const float gap = t == 4 ? 0.f : row_gap_sq(g, y, z, cy, cz, qy, qz);
+      if (gap >= worst) continue;
+      const int v0 = lds_bounds[(t * 4 + 0) * kKnnBlock], v1 = lds_bounds[(t * 4 + 1) * kKnnBlock], v2 = lds_bounds[(t * 4 + 2) * kKnnBlock],
+                v3 = lds_bounds[(t * 4 + 3) * kKnnBlock];
+      const int s = cx > 0 ? v0 : v1, e = cx < g.nx - 1 ? v3 : v2;
+      if (e <= s) continue;
+      const int m = (t == 4 && p >= 0) ? p : v1 + (int)(fx * (float)(v2 - v1));
+      knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst);
+    }
+  }
+  // ---- rings 2, 3, ... while the k-th best is not provably exact: the rows on the frame of the (2r+1)^2 window (runs cx-r..cx+r)
+  //      and, for the rows inside the frame, the two end cells cx-r and cx+r ----
   const int rmax = max(max(g.nx, g.ny), g.nz);
-  for (int r = 1; r <= rmax + 1; ++r) {  // r = 1 stands for rings 0 and 1 together
-    if (r >= 2 && worst <= unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r - 1)) break;
+  for (int r = 2; r <= rmax + 1; ++r) {
+    if (worst <= unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, r - 1)) break;
     const int xa = max(cx - r, 0), xb = min(cx + r, g.nx - 1);
     const float frac = fminf(fmaxf((qx - (g.ox + (float)xa * g.h)) / ((float)(xb + 1 - xa) * g.h), 0.f), 1.f);
     // lower bounds of |dx| to the two end cells of an inner row (cells cx-r and cx+r)
     const float xl = fmaxf(qx - (g.ox + (float)(cx - r + 1) * g.h) - g.slack, 0.f), xr = fmaxf((g.ox + (float)(cx + r) * g.h) - qx - g.slack, 0.f);
     const int side = 2 * r + 1;
     for (int t = 0; t < side * side; ++t) {
-      const int tt = r > 1 ? t : (t == 0 ? 4 : (t <= 4 ? t - 1 : t));  // rings 0..1: the query's own row first
-      const int dz = tt / side - r, dy = tt % side - r;
+      const int dz = t / side - r, dy = t % side - r;
       const int y = cy + dy, z = cz + dz;
       if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
       const float gap = row_gap_sq(g, y, z, cy, cz, qy, qz);
       if (gap >= worst) continue;
       const int row = (z * g.ny + y) * g.nx;
-      const bool full = r == 1 || dz == -r || dz == r || dy == -r || dy == r;  // else an inner row: only its two end cells are new
+      const bool full = dz == -r || dz == r || dy == -r || dy == r;  // else an inner row: only its two end cells are new
       for (int u = 0; u < (full ? 1 : 2); ++u) {
         int c0, c1, m_hint;  // cells [c0, c1] of the row; where to start (0: interpolate, 1: the run's last point, 2: its first)
         if (full) {
@@ -180,8 +215,7 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
         }
         const int s = cell_start[row + c0], e = cell_start[row + c1 + 1];
         if (e <= s) continue;
-        int m = m_hint == 1 ? e - 1 : (m_hint == 2 ? s : s + (int)(frac * (float)(e - s)));
-        if (r == 1 && tt == 4 && p >= 0) m = p;  // the query is a point of this cloud: start at itself
+        const int m = m_hint == 1 ? e - 1 : (m_hint == 2 ? s : s + (int)(frac * (float)(e - s)));
         knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst);
       }
     }
@@ -195,13 +229,14 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
 enum { REG_NONE = 0, REG_MIN_EIG = 1, REG_NORMALIZED_MIN_EIG = 2, REG_PLANE = 3, REG_FROBENIUS = 4 };
 
 template <int K>
-__global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int n, int k, int reg,
-                                                      double* __restrict__ covs6) {
+__global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int n, int k, int reg,
+                                                            double* __restrict__ covs6) {
+  __shared__ int lds_bounds[36 * kKnnBlock];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float4 q = sorted[i];
   TopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top);
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top, lds_bounds + threadIdx.x);
 
   // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k
   double mx = 0, my = 0, mz = 0;
@@ -273,13 +308,14 @@ __global__ void __launch_bounds__(128) k_covariances(const float4* __restrict__ 
 
 // Test hook: exact kNN of arbitrary queries (float4 xyz_) in an indexed cloud; outputs ORIGINAL indices.
 template <int K>
-__global__ void __launch_bounds__(128) k_knn_queries(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, const float4* __restrict__ queries,
+__global__ void __launch_bounds__(kKnnBlock) k_knn_queries(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, const float4* __restrict__ queries,
                                                       int nq, int k, int* __restrict__ out_idx, float* __restrict__ out_d2) {
+  __shared__ int lds_bounds[36 * kKnnBlock];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   const float4 q = queries[i];
   TopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top);
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top, lds_bounds + threadIdx.x);
   static_for<0, K>([&](auto S) {
     if (S.value < k) {
       const int pos = top.template id<S.value>();
