@@ -107,6 +107,33 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const floa
 // Every position is visited at most once (no duplicates in the list).  Ties: the first visited stays in front (strict '<'), like
 // KNNResultSet::addPoint (impl/nanoflann_impl.hpp:184-211); the visiting order is not a kd-tree's, so among EXACTLY equal
 // distances another index may be kept (SURVEY.md §7 "Ties").
+// The eight points of a window (positions w .. w+7; `valid`: which of them belong to the run) against the list.  A candidate is
+// inserted by a K-step predicated shift that the WHOLE wave executes whenever any lane inserts; taking the eight positions in turn
+// would run it eight times per window although a lane typically has 0-3 candidates that beat its k-th best, so each lane first
+// marks its passing candidates and the wave loops over the lanes' marks: as many insert rounds as the busiest lane needs.
+// Candidates are still taken in increasing position (first visited stays in front among equal distances).
+template <int K>
+__device__ __forceinline__ void knn_take_window(const float4 (&c)[8], int w, unsigned int valid, float qx, float qy, float qz, int k, TopK<K>& top, float& worst) {
+  float d[8];
+  unsigned int mask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    d[j] = sqdist(qx, qy, qz, c[j]);
+    if (((valid >> j) & 1u) && d[j] < worst) mask |= 1u << j;
+  }
+  while (mask) {
+    const int j = __ffs((int)mask) - 1;
+    mask &= mask - 1;
+    float dj = d[0];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) dj = (j == t) ? d[t] : dj;
+    if (dj < worst) {  // (the bound may have tightened since the candidate was marked)
+      top.insert(dj, w + j);
+      worst = fminf(worst, top.kth(k));
+    }
+  }
+}
+
 template <int K>
 __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, int s, int e, int m, float qx, float qy, float qz, float gap, int k, TopK<K>& top,
                                              float& worst) {
@@ -115,14 +142,7 @@ __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, 
     float4 c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) c[j] = sorted[min(w + j, e - 1)];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = sqdist(qx, qy, qz, c[j]);
-      if (w + j < e && d < worst) {
-        top.insert(d, w + j);
-        worst = fminf(worst, top.kth(k));
-      }
-    }
+    knn_take_window<K>(c, w, w + 8 <= e ? 0xffu : (0xffu >> (w + 8 - e)), qx, qy, qz, k, top, worst);
     const float dr = c[7].x - qx;  // the window's (or the run's) last point: everything beyond has a larger x
     if (dr > 0.f && dr * dr + gap > worst) break;
   }
@@ -130,14 +150,7 @@ __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, 
     float4 c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) c[j] = sorted[max(w + j, s)];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = sqdist(qx, qy, qz, c[j]);
-      if (w + j >= s && d < worst) {
-        top.insert(d, w + j);
-        worst = fminf(worst, top.kth(k));
-      }
-    }
+    knn_take_window<K>(c, w, w >= s ? 0xffu : ((0xffu << (s - w)) & 0xffu), qx, qy, qz, k, top, worst);
     const float dl = qx - c[0].x;
     if (dl > 0.f && dl * dl + gap > worst) break;
   }
