@@ -1,13 +1,11 @@
 #!/bin/bash
-# Profiles of the bench workload on the GPU box (run through gpurun).  Outputs under gpurun_out/prof_r01/.
-# PMC counters are collected in their own passes (no tracing domains mixed in), as the pool requires.
+# rocprofv3 kernel trace + stats of the bench command itself (the numbers bench.py's roofline block must agree with).
+# Output: gpurun_out/prof_bench/...; scripts/summarize_bench_profile.py copies the summary into profiles/.
 set -o pipefail
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_r01
-mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_write.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/pmc_l2 -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_l2.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_sq.log 2>&1 || exit 1
-echo profiles done
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd /tmp && export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/prof_bench
+rm -rf $OUT; mkdir -p $OUT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_trace.log 2>&1 || { tail -5 $OUT/bench_trace.log; exit 1; }
+grep "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench_under_rocprof.json
+echo bench profile done

@@ -1,0 +1,27 @@
+"""gpurun_out/prof_bench (scripts/profile_bench.sh) -> profiles/<tag>_bench_kernel_stats.csv + <tag>_bench_under_rocprof.json (+ the working-launch
+averages of the two hot kernels, which the bench line's HIP-event figure must agree with)."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", "prof_bench")
+DST = os.path.join(ROOT, "profiles")
+stats = glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows:
+        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+trace = glob.glob(os.path.join(SRC, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
+durs = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+pk = next(k for k in durs if "k_gicp_pass" in k); sk = next(k for k in durs if "k_lm_solve" in k)
+work = [d for d in durs[pk] if d > 15.0]; swork = [d for d in durs[sk] if d > 3.0]
+line = json.load(open(os.path.join(SRC, "bench_under_rocprof.json")))
+out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras",
+       "k_gicp_pass_working_launches": len(work), "k_gicp_pass_avg_us_working": sum(work) / len(work),
+       "k_lm_solve_working_launches": len(swork), "k_lm_solve_avg_us_working": sum(swork) / len(swork),
+       "bench_line_avg_launch_us_hip_events": line["roofline"]["avg_launch_ms"] * 1e3, "bench_line": line}
+json.dump(out, open(os.path.join(DST, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "bench_line"}, indent=1))
