@@ -246,7 +246,7 @@ struct Params {
 struct ngicp {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_poll[2] = {nullptr, nullptr};
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipEvent_t ev_cov_a = nullptr, ev_cov_b = nullptr;  // around the last covariance kernel; read lazily (ngicp_get_stats)
   hipEvent_t ev_fence = nullptr;                       // fence_engine_streams()
   bool cov_timing_pending = false;
@@ -254,7 +254,7 @@ struct ngicp {
   Params p;
   double voxel_size = 0.0;  // 0 = auto
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
-  int chunk_pairs = 4;      // (pass, solve) pairs enqueued between two polls of the done flag (env NGICP_CHUNK)
+  int chunk_pairs = 3;      // (pass, solve) pairs kept in flight ahead of the solver's published progress (env NGICP_CHUNK)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
   std::pair<size_t, double> voxel_memo[2] = {{0, 0.0}, {0, 0.0}};  // {cloud size, auto voxel edge} of recent builds
   bool profiling = false;
@@ -270,7 +270,7 @@ struct ngicp {
   int order_groups = -1;
   DevBuf tpt[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
-  int* h_poll = nullptr;  // pinned: done flags
+  int* h_progress = nullptr;  // pinned: {passes done | kProgressDone}, written by the solver (SolveArgs::progress_host)
   LmState* pin_state = nullptr;  // pinned [2]: the state image an align uploads / the one it reads back (no staging copies)
   int hook_valid = 0;     // 1: the linearize hook has produced correspondences; 2: an align has (indices of its last linearisation)
 
@@ -715,6 +715,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.mode = 0;
   s.sums_out = nullptr;
   s.dbg_stamps = nullptr;
+  s.progress_host = nullptr;
   c.nblocks = nblocks;
   h->stats.lanes_per_query = 2;
   h->stats.voxel_size = T.grid.h;
@@ -830,34 +831,32 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     c.pa.dbg_qstats = h->dbg_q.as<int4>();
   }
   const long max_passes = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? (long)h->p.max_iter : (long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1;
-  int chunk = h->chunk_pairs;
+  // The host feeds (pass, solve) pairs to the stream and never blocks on it inside the loop: the solver publishes its progress
+  // {passes done, done flag} in PINNED host memory (one system-scope store), the host keeps `depth` pairs in flight and stops
+  // feeding when it sees the flag.  At most `depth` pairs are enqueued in vain (they return at once: the state says done);
+  // round 1 polled a copied flag one chunk of four pairs behind and wasted up to eight.
+  const int depth = h->chunk_pairs;
+  *h->h_progress = 0;
+  c.sa.progress_host = h->h_progress;
   HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   long launched = 0;
-  int slot = 0;
-  bool pending[2] = {false, false};
-  LmState* dst = h->state.as<LmState>();
   bool finished = (h->p.max_iter <= 0);
+  const double t_loop = now_ms();
+  unsigned long spins = 0;
   while (!finished && launched < max_passes) {
-    // one chunk ahead: before enqueuing chunk c+2, look at the flag recorded after chunk c
-    if (pending[slot]) {
-      HIP_TRY(hipEventSynchronize(h->ev_poll[slot]));
-      pending[slot] = false;
-      if (h->h_poll[slot]) {
-        finished = true;
-        break;
-      }
+    const int prog = *reinterpret_cast<volatile int*>(h->h_progress);
+    if (prog & kProgressDone) break;
+    if (launched - (long)(prog & kProgressMask) >= depth) {  // enough in flight: wait for the device to catch up
+      if ((++spins & 0xfffff) == 0 && now_ms() - t_loop > 30000.0) throw ArgError{NGICP_ERR_HIP, "the registration loop did not finish within 30 s"};
+      __builtin_ia32_pause();
+      continue;
     }
-    for (int i = 0; i < chunk && launched < max_passes; ++i, ++launched) {
-      const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
-      if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched], h->stream));
-      launch_pass(h, c.pa, c.nblocks, h->stream);
-      if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched + 1], h->stream));
-      hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
-    }
-    HIP_TRY(hipMemcpyAsync(&h->h_poll[slot], &dst->hot.done, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->ev_poll[slot], h->stream));
-    pending[slot] = true;
-    slot ^= 1;
+    const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
+    if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched], h->stream));
+    launch_pass(h, c.pa, c.nblocks, h->stream);
+    if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched + 1], h->stream));
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
+    ++launched;
   }
   HIP_TRY(hipEventRecord(h->ev_b, h->stream));
   HIP_TRY(hipMemcpyAsync(&h->pin_state[1], h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
@@ -1011,11 +1010,9 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipEventCreate(&h->ev_cov_a));
     HIP_TRY(hipEventCreate(&h->ev_cov_b));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fence, hipEventDisableTiming));
-    HIP_TRY(hipEventCreate(&h->ev_poll[0]));
-    HIP_TRY(hipEventCreate(&h->ev_poll[1]));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_poll), 2 * sizeof(int), hipHostMallocDefault));
-    h->h_poll[0] = h->h_poll[1] = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_state), 2 * sizeof(LmState), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));
+    *h->h_progress = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_shard_done), kShardSlots * sizeof(int), hipHostMallocDefault));
     for (int i = 0; i < kShardSlots; ++i) {
       h->h_shard_done[i] = 0;
@@ -1061,8 +1058,8 @@ int ngicp_destroy(ngicp_t* h) {
   h->tgt_covs.clear();
   for (auto& e : h->prof_events)
     if (e) (void)hipEventDestroy(e);
-  if (h->h_poll) (void)hipHostFree(h->h_poll);
   if (h->pin_state) (void)hipHostFree(h->pin_state);
+  if (h->h_progress) (void)hipHostFree(h->h_progress);
   if (h->h_shard_done) (void)hipHostFree(h->h_shard_done);
   for (auto& e : h->ev_shard)
     if (e) (void)hipEventDestroy(e);
@@ -1071,8 +1068,6 @@ int ngicp_destroy(ngicp_t* h) {
   if (h->ev_cov_a) (void)hipEventDestroy(h->ev_cov_a);
   if (h->ev_cov_b) (void)hipEventDestroy(h->ev_cov_b);
   if (h->ev_fence) (void)hipEventDestroy(h->ev_fence);
-  for (int i = 0; i < 2; ++i)
-    if (h->ev_poll[i]) (void)hipEventDestroy(h->ev_poll[i]);
   ngk_filter_free(&h->fws);
   hipStream_t s = h->stream;
   delete h;

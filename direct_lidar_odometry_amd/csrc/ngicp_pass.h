@@ -813,7 +813,9 @@ struct SolveArgs {
   int* grp_order;          // [nblocks] out: groups sorted by measured cost, heaviest first (mode 0 only), or null
   const int* grp_cost;     // [nblocks] in: duration of each group's block in the pass just finished
   unsigned long long* dbg_stamps;  // diagnostic only: [8] s_memtime stamps of the last launch, or null
+  int* progress_host;      // pinned host memory, or null: {passes done | kProgressDone} published after every step (mode 0)
 };
+constexpr int kProgressDone = 1 << 30, kProgressMask = kProgressDone - 1;
 
 __device__ __forceinline__ bool is_converged_dev(const Pose& d, double rot_eps, double trans_eps) {  // impl/lsq_registration_impl.hpp:118-127
   double rmax = 0.0, tmax = 0.0;
@@ -1106,6 +1108,9 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
+  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag)
+  if (a.mode == 0 && a.progress_host && lane == 0)
+    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   NG_SSTAMP(6);
 #undef NG_SSTAMP
 }
