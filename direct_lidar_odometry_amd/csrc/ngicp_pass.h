@@ -491,48 +491,6 @@ __global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a)
       const bool in_box = qok && listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
       unsigned int dbg_g1 = 0, dbg_g2 = 0;
       auto pack_key = [](float d, int p) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)p; };
-      // One step of a walk over the x-sorted run [s0, e0): the window [w, w + W), read in increasing position, so that c[0] / c[W-1]
-      // are its smallest / largest x and, among equal distances, the first one met has the smallest position (strict `<`).  No
-      // index clamps: a window that overhangs the run reads points of the neighbouring runs (genuine target points: they can only
-      // be legitimate candidates) or the sentinels that frame the array; the x-gap tests only look at c[W-1] / c[0] when the
-      // window's right / left end is inside the run.  The walk goes right while that side is alive, then left; returns true when
-      // it is over (the caller publishes (ub, up)).
-      auto walk_step = [&](int qs, int s0, int e0, int& w, int& lo, int& hi, int& dir, int& up, bool& go_left, float gyz, float& ub, float ux, float uy, float uz,
-                           unsigned int& steps) -> bool {
-        constexpr int W = kWalkWindow;
-        const float4* __restrict__ wp = a.tgt + w;
-        float4 c[W];
-#pragma unroll
-        for (int j = 0; j < W; ++j) c[j] = wp[j];
-        float lb = sqdist(ux, uy, uz, c[0]);
-        int lj = 0;
-#pragma unroll
-        for (int j = 1; j < W; ++j) {
-          const float d = sqdist(ux, uy, uz, c[j]);
-          if (d < lb) { lb = d; lj = j; }
-        }
-        if (nn_better(lb, w + lj, ub, up)) { ub = lb; up = w + lj; }
-        ncand += W;
-        ++steps;
-        (void)qs;
-        const float lim = fminf(ub, a.gate_sq_f), dr = c[W - 1].x - ux, dl = ux - c[0].x;
-        const bool more_right = hi < e0 && !(dr > 0.f && dr * dr + gyz > lim);
-        const bool more_left = lo > s0 && !(dl > 0.f && dl * dl + gyz > lim);
-        if (dir == 0) go_left = more_left;
-        if (dir >= 0 && more_right) {
-          dir = 1;
-          w = hi;
-          hi += W;
-          return false;
-        }
-        if (dir >= 0 ? go_left : more_left) {
-          dir = -1;
-          lo -= W;
-          w = lo;
-          return false;
-        }
-        return true;
-      };
       // ---- rings 0..1.  The 3 x 3 window of (y,z) rows around the query's cell; a row of it is the x-sorted run of the cells
       //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
       //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it).  Every
@@ -586,53 +544,25 @@ __global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a)
       wave_lds_sync();
       NG_STAMP(16);
       {
-        // ONE loop pops and walks: every iteration a lane either takes a unit off the queue or makes one window step of the walk
-        // it is in.  (With the walk as an inner loop the whole wave sat through the longest walk of every pop round - the
-        // average walk is 1.8 windows, the longest of 64 about 4-5 - and only then popped again.)
         const int tail = S.q_tail;
         unsigned int popped = 0;
-        bool have = false, exhausted = false;
-        int qs = 0, s0 = 0, e0 = 0, w = 0, lo = 0, hi = 0, dir = 0, up = -1;
-        bool go_left = false;
-        float gyz = 0.f, ub = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
-        constexpr int W = kWalkWindow;
         for (;;) {
-          if (!have && !exhausted) {
-            const int u = atomicAdd(&S.q_head, 1);
-            if (u < tail) {
-              ++popped;
-              const int uq = S.unit_q[u];
-              qs = uq & 31;
-              s0 = S.unit_s[u];
-              e0 = S.unit_e[u];
-              gyz = S.unit_g[u];
-              const float4 q = S.qtab[qs];
-              ux = q.x; uy = q.y; uz = q.z;
-              const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
-              ub = __uint_as_float((unsigned int)(k0 >> 32));
-              up = (int)(unsigned int)k0;
-              if (!(gyz > fminf(ub, a.gate_sq_f))) {  // (else: ruled out meanwhile; the lane pops again next time round)
-                const int m = min(max(s0 + (uq >> 9), s0), e0 - 1);
-                w = lo = m - W / 2;
-                hi = w + W;
-                dir = 0;
-                have = true;
-                if (a.dbg_qstats) atomicAdd(&S.qstat[qs][1], 1);
-              }
-            } else {
-              exhausted = true;
-            }
-          }
-          if (!__any(have)) {
-            if (__all(exhausted)) break;
-            continue;
-          }
-          if (have) {
-            if (a.dbg_qstats) atomicAdd(&S.qstat[qs][0], W);
-            if (walk_step(qs, s0, e0, w, lo, hi, dir, up, go_left, gyz, ub, ux, uy, uz, dbg_g1)) {
-              atomicMin(&S.qkey[qs], pack_key(ub, up));
-              have = false;
-            }
+          const int u = atomicAdd(&S.q_head, 1);
+          if (u >= tail) break;
+          ++popped;
+          const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
+          const float gyz = S.unit_g[u];
+          const float4 q = S.qtab[qs];
+          const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
+          float ub = __uint_as_float((unsigned int)(k0 >> 32));
+          int up = (int)(unsigned int)k0;
+          if (gyz > fminf(ub, a.gate_sq_f)) continue;
+          const unsigned int c_before = ncand;
+          scan_global_outward(a.tgt, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          atomicMin(&S.qkey[qs], pack_key(ub, up));
+          if (a.dbg_qstats) {
+            atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
+            atomicAdd(&S.qstat[qs][1], 1);
           }
         }
         NG_STAMP(17);
@@ -680,55 +610,31 @@ __global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a)
           wave_lds_sync();
           {
             const int tail = min(S.q_tail, kUnitCap);
-            bool have = false, exhausted = false;
-            int qs = 0, s0 = 0, e0 = 0, w = 0, lo = 0, hi = 0, dir = 0, up = -1;
-            bool go_left = false;
-            float gyz = 0.f, ub = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
-            constexpr int W = kWalkWindow;
-            for (;;) {  // pop and walk in one loop, as in ring 1
-              if (!have && !exhausted) {
-                const int u = atomicAdd(&S.q_head, 1);
-                if (u < tail) {
-                  const int unit = S.unit_q[u];
-                  qs = unit & 31;
-                  const int4 rec = S.live[unit >> 5];
-                  const float4 q = S.qtab[qs];
-                  ux = q.x; uy = q.y; uz = q.z;
-                  int cxq, cyq, czq;
-                  cell_coords(g, q.x, q.y, q.z, cxq, cyq, czq);
-                  gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cyq, czq, q.y, q.z);
-                  const unsigned long long k0 = S.qkey[qs];
-                  ub = __uint_as_float((unsigned int)(k0 >> 32));
-                  up = (int)(unsigned int)k0;
-                  if (!(gyz > fminf(ub, a.gate_sq_f))) {
-                    // start where qx sits inside its own cell of the row (one extra round trip, but a much better start than
-                    // interpolating over the whole region row; the previous correspondence when it lies in the row)
-                    struct alignas(4) Bounds4 { int v[4]; };
-                    const Bounds4 bq = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + (((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx + cxq - 1));
-                    const float fxq = fminf(fmaxf((q.x - (g.ox + (float)cxq * g.h)) * g.inv_h, 0.f), 1.f);
-                    s0 = rec.z;
-                    e0 = rec.z + rec.y;
-                    const int m = (up >= s0 && up < e0) ? up : min(max(bq.v[1] + (int)(fxq * (float)(bq.v[2] - bq.v[1])), s0), e0 - 1);
-                    w = lo = m - W / 2;
-                    hi = w + W;
-                    dir = 0;
-                    have = true;
-                    if (a.dbg_qstats) atomicAdd(&S.qstat[qs][1], 1 << 16);
-                  }
-                } else {
-                  exhausted = true;
-                }
-              }
-              if (!__any(have)) {
-                if (__all(exhausted)) break;
-                continue;
-              }
-              if (have) {
-                if (a.dbg_qstats) atomicAdd(&S.qstat[qs][2], W);
-                if (walk_step(qs, s0, e0, w, lo, hi, dir, up, go_left, gyz, ub, ux, uy, uz, dbg_g2)) {
-                  atomicMin(&S.qkey[qs], pack_key(ub, up));
-                  have = false;
-                }
+            for (;;) {
+              const int u = atomicAdd(&S.q_head, 1);
+              if (u >= tail) break;
+              const int unit = S.unit_q[u], qs = unit & 31;
+              const int4 rec = S.live[unit >> 5];
+              const float4 q = S.qtab[qs];
+              int ux, uy, uz;
+              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
+              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, uy, uz, q.y, q.z);
+              const unsigned long long k0 = S.qkey[qs];
+              float ub = __uint_as_float((unsigned int)(k0 >> 32));
+              int up = (int)(unsigned int)k0;
+              if (gyz > fminf(ub, a.gate_sq_f)) continue;
+              // start where qx sits among the row's three centre cells (one extra round trip, but a much better start
+              // than interpolating over the whole region row: the walk is over the whole row either way)
+              const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1;
+              const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
+              const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
+              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+              const unsigned int c_before = ncand;
+              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              atomicMin(&S.qkey[qs], pack_key(ub, up));
+              if (a.dbg_qstats) {
+                atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
+                atomicAdd(&S.qstat[qs][1], 1 << 16);
               }
             }
           }
