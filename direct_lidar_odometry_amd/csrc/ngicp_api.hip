@@ -1120,6 +1120,10 @@ int ngicp_set_target(ngicp_t* h, const float* xyz, size_t n, size_t stride_bytes
   const bool same = (id != 0 && h->tgt.present && h->tgt.identity == id);
   int rc = set_cloud(h, h->tgt, xyz, n, stride_bytes, id, true);
   if (rc == NGICP_OK && !same) h->tgt_covs.clear();  // :138
+  if (!same) {  // the target is no longer the submap assembled by ngicp_submap_set (a recycled index object may reuse its address)
+    h->submap_cloud = nullptr;
+    h->submap_ids.clear();
+  }
   return rc;
 }
 int ngicp_clear_source(ngicp_t* h) {
@@ -1132,6 +1136,8 @@ int ngicp_clear_target(ngicp_t* h) {
   return guarded(h, [&] {
     h->tgt.clear();
     h->tgt_covs.clear();
+    h->submap_cloud = nullptr;
+    h->submap_ids.clear();
   });
 }
 
@@ -1158,6 +1164,8 @@ int ngicp_swap_source_target(ngicp_t* h) {
     std::swap(h->src, h->tgt);
     std::swap(h->src_covs, h->tgt_covs);
     h->hook_valid = 0;  // correspondences_.clear(); sq_distances_.clear();
+    h->submap_cloud = nullptr;
+    h->submap_ids.clear();
   });
 }
 

@@ -84,9 +84,14 @@ def test_submap_subsets_order_and_errors(ng, oracle_mod):
         ref.setInputSource(w.source); ref.setInputTarget(np.concatenate([kfs[i] for i in ids])); ref.setTargetCovariances(np.concatenate([normals[i] for i in ids]))
         ref.align(w.guess)
         assert np.array_equal(s2m.getFinalTransformation(), ref.getFinalTransformation())
-    # a host target replaces the submap; the same ids then rebuild it
+    # a host target replaces the submap; the same ids then rebuild it (also when the host cloud has the submap's size and the
+    # recycled index object its address)
     s2m.setInputTarget(kfs[0]); s2m.setTargetCovariances(normals[0])
     assert s2m.setSubmapKeyframes([0, 1, 2, 3]) is True
+    same_size = np.ascontiguousarray(w.target[::-1])
+    s2m.setInputTarget(same_size); s2m.setTargetCovariances(np.concatenate(normals)[::-1])
+    assert s2m.setSubmapKeyframes([0, 1, 2, 3]) is True
+    assert np.array_equal(s2m.targetPoints(), w.target)
     with pytest.raises(ng.NgicpError):
         s2m.setSubmapKeyframes([0, 7])
     with pytest.raises(ng.NgicpError):
