@@ -800,6 +800,7 @@ __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r 
 constexpr int kMaxOrderGroups = 8192;  // launch-order sort: groups whose costs fit the solver's LDS
 constexpr int kSolveThreads = 512;  // 8 waves = 2 per SIMD: the serial lane keeps a 256-VGPR budget, the reduction gets 512 loaders
 constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (thread = 16 slot pairs x 32 group subsets)
+constexpr int kSolveChunk = 48;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 48 = 1536 groups
 
 struct SolveArgs {
   LmState* st;
@@ -951,17 +952,17 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   } while (0)
   NG_SSTAMP(0);
   // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
-  //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, 32 sixteen-byte loads in flight per step (one step
-  //      covers 1024 groups: the whole c3 grid in a single memory round trip); the 32 subset sums of a slot are then added
+  //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
+  //      covers 1536 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
   //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass.
   //      The first step's loads are issued BEFORE anything else, so that the staging loads below (state image, group costs)
   //      share their round trip instead of preceding it. ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
   const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
-  double2 p[32];
+  double2 p[kSolveChunk];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
+  for (int j = 0; j < kSolveChunk; ++j) {
     const int gi = sb + j * kSolveSubs;
     p[j] = gi < a.nblocks ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
   }
@@ -985,18 +986,18 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   {
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < kSolveChunk; ++j) {
       a0 += p[j].x;
       a1 += p[j].y;
     }
-    for (int g0 = sb + kSolveSubs * 32; g0 < a.nblocks; g0 += kSolveSubs * 32) {  // grids beyond 1024 groups: further steps
+    for (int g0 = sb + kSolveSubs * kSolveChunk; g0 < a.nblocks; g0 += kSolveSubs * kSolveChunk) {  // larger grids: further steps
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
+      for (int j = 0; j < kSolveChunk; ++j) {
         const int gi = g0 + j * kSolveSubs;
         p[j] = gi < a.nblocks ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
       }
 #pragma unroll
-      for (int j = 0; j < 32; ++j) {
+      for (int j = 0; j < kSolveChunk; ++j) {
         a0 += p[j].x;
         a1 += p[j].y;
       }
@@ -1103,14 +1104,15 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
       }
     }
   }
+  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag);
+  // issued before the state goes back so that the PCIe write overlaps it
+  if (a.mode == 0 && a.progress_host && lane == 0)
+    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // wave 0 stores the state image back (lane 0's LDS writes are ordered before the other lanes' reads by the fence pair)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
-  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag)
-  if (a.mode == 0 && a.progress_host && lane == 0)
-    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   NG_SSTAMP(6);
 #undef NG_SSTAMP
 }
