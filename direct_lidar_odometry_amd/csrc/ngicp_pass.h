@@ -800,7 +800,10 @@ __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r 
 constexpr int kMaxOrderGroups = 8192;  // launch-order sort: groups whose costs fit the solver's LDS
 constexpr int kSolveThreads = 512;  // 8 waves = 2 per SIMD: the serial lane keeps a 256-VGPR budget, the reduction gets 512 loaders
 constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (thread = 16 slot pairs x 32 group subsets)
-constexpr int kSolveChunk = 48;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 48 = 1536 groups
+#ifndef NGICP_SOLVE_CHUNK
+#define NGICP_SOLVE_CHUNK 48
+#endif
+constexpr int kSolveChunk = NGICP_SOLVE_CHUNK;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 48 = 1536 groups
 
 struct SolveArgs {
   LmState* st;
@@ -943,7 +946,6 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
 __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ double wsum[kSolveSubs][kPartialStride];
   __shared__ double sums[kPartialStride];
-  __shared__ int ord_cnt[16], ord_pos[16], ord_max;
   __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
 #define NG_SSTAMP(k)                                                                 \
@@ -1020,36 +1022,48 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
   if (order_it && wave == 1) {
     // ---- launch order of the next pass, built by wave 1 (costs already in LDS) while lane 0 runs the state machine:
-    //      16 cost classes relative to the slowest group, heaviest class first.  The order inside a class is whatever
-    //      the LDS atomics make it: the pass's results do not depend on the launch order. ----
-    auto wsync = [] {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    if (lane < 16) ord_cnt[lane] = 0;
-    if (lane == 0) ord_max = 1;
-    wsync();
-    int mx = 0;
+    //      16 cost classes relative to the slowest group, heaviest class first.  (The pass's results do not depend on the
+    //      launch order.) ----
+    // No LDS atomics: 64 lanes hammering 16 counters serialise (2170 groups at c5 cost ~10 us that way, more than everything else in
+    // this kernel).  The wave walks the groups 64 at a time and keeps the 16 class counters / write positions in uniform registers:
+    // a ballot per class gives every lane its rank inside its class.
+    int mx = 1;
     for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, ord_cost[gi]);
-    atomicMax(&ord_max, mx);
-    wsync();
-    const long long M = (long long)ord_max + 1;
-    for (int gi = lane; gi < a.nblocks; gi += 64) {
-      const int c = 15 - (int)(((long long)ord_cost[gi] * 16) / M);
-      ord_cost[gi] = c;  // the class replaces the cost
-      atomicAdd(&ord_cnt[c], 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    const float to_class = 16.0f / ((float)mx + 1.0f);  // (a heuristic: float rounding at class boundaries is immaterial)
+    int cnt[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cnt[c] = 0;
+    for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
+      const int gi = g0 + lane;
+      const int cls = gi < a.nblocks ? 15 - min(15, (int)((float)ord_cost[gi] * to_class)) : -1;
+      if (gi < a.nblocks) ord_cost[gi] = cls;  // the class replaces the cost
+#pragma unroll
+      for (int c = 0; c < 16; ++c) cnt[c] += __popcll(__ballot(cls == c));
     }
-    wsync();
-    if (lane == 0) {
+    int pos[16];
+    {
       int run = 0;
+#pragma unroll
       for (int c = 0; c < 16; ++c) {
-        ord_pos[c] = run;
-        run += ord_cnt[c];
+        pos[c] = run;
+        run += cnt[c];
       }
     }
-    wsync();
-    for (int gi = lane; gi < a.nblocks; gi += 64) a.grp_order[atomicAdd(&ord_pos[ord_cost[gi]], 1)] = gi;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
+      const int gi = g0 + lane;
+      const int cls = gi < a.nblocks ? ord_cost[gi] : -1;
+      int dst = 0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) dst = pos[c] + __popcll(m & lt);
+        pos[c] += __popcll(m);
+      }
+      if (gi < a.nblocks) a.grp_order[dst] = gi;  // within a class: ascending group index (deterministic, though nothing depends on it)
+    }
     if (lane == 0) st->order_valid = 1;
   }
   if (wave != 0) return;

@@ -8,7 +8,7 @@ procs = []
 for spec in sys.argv[1:]:
     name, flags = spec.split("=", 1)
     out = os.path.join(ROOT, "variants", f"libngicp_{name}.so")
-    cmd = [b.hipcc(), *b.FLAGS, *[f for f in flags.split(",") if f], os.path.join(b.CSRC, "ngicp_api.hip"), "-o", out]
+    cmd = [b.hipcc(), *b.FLAGS, *[f for f in flags.split(",") if f], *[os.path.join(b.CSRC, src) for src in b.SOURCES], "-o", out]
     procs.append((name, subprocess.Popen(cmd)))
 for name, p in procs:
     print(name, "rc", p.wait())
