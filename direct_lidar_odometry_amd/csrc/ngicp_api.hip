@@ -877,8 +877,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   if (c.sa.dbg_stamps) {
     unsigned long long ts[8];
     HIP_TRY(hipMemcpy(ts, h->dbg_s.p, sizeof(ts), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "k_lm_solve stamps (cycles since entry): loads issued %llu, reduced %llu, state in registers %llu, lm_advance %llu, accept path %llu, stored %llu\n",
-                 ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[4] - ts[0], ts[5] - ts[0], ts[6] - ts[0]);
+    std::fprintf(stderr, "k_lm_solve stamps (cycles since entry): loads issued %llu, reduced %llu, state in registers %llu, lm_advance %llu, accept path %llu, stored %llu; launch-order section (wave 1) %llu cycles\n",
+                 ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[4] - ts[0], ts[5] - ts[0], ts[6] - ts[0], ts[7]);
   }
   if (qstat_path) {
     std::vector<int> hq((size_t)c.pa.n_src * 4);

@@ -946,13 +946,14 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
 __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ double wsum[kSolveSubs][kPartialStride];
   __shared__ double sums[kPartialStride];
+  __shared__ int ord_cnt[16], ord_pos[16];
   __shared__ int ord_cost[kMaxOrderGroups];
   LmState* st = a.st;
 #define NG_SSTAMP(k)                                                                 \
   do {                                                                               \
     if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
-  NG_SSTAMP(0);
+  if (a.dbg_stamps && threadIdx.x == 0 && !st->hot.done) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
   // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
   //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
   //      covers 1536 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
@@ -1020,51 +1021,70 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   NG_SSTAMP(2);
   if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
   if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
-  if (order_it && wave == 1) {
+  // (The order is refreshed after the first two passes of an alignment and then after every fourth: group costs move slowly, and
+  // at 7 us for 866 groups / 17 us for 2170 this section, not the state machine, would otherwise end the kernel.)
+  if (order_it && wave == 1 && (L.passes < 2 || (L.passes & 3) == 1)) {
+    const unsigned long long t_ord = a.dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
     // ---- launch order of the next pass, built by wave 1 (costs already in LDS) while lane 0 runs the state machine:
     //      16 cost classes relative to the slowest group, heaviest class first.  (The pass's results do not depend on the
     //      launch order.) ----
-    // No LDS atomics: 64 lanes hammering 16 counters serialise (2170 groups at c5 cost ~10 us that way, more than everything else in
-    // this kernel).  The wave walks the groups 64 at a time and keeps the 16 class counters / write positions in uniform registers:
-    // a ballot per class gives every lane its rank inside its class.
+    // A lone wave issues about one instruction per 4-5 cycles, so this section is instruction-bound and sits on the kernel's critical
+    // path at large grids (2170 groups at c5).  No per-lane atomics and no per-class loops: four ballots (one per bit of the class)
+    // give every lane the mask of the lanes that share its class; its rank is a popcount, and the lowest lane of each class moves
+    // the class's counter in LDS (distinct addresses per class: no conflicts; same-wave LDS operations are ordered).
+    auto wsync = [] {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto same_class = [&](int cls, bool valid) -> unsigned long long {
+      unsigned long long m = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const bool one = (cls >> bit) & 1;
+        const unsigned long long bb = __ballot(valid && one);
+        m &= one ? bb : ~bb;
+      }
+      return m;
+    };
+    if (lane < 16) ord_cnt[lane] = 0;
     int mx = 1;
     for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, ord_cost[gi]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
     const float to_class = 16.0f / ((float)mx + 1.0f);  // (a heuristic: float rounding at class boundaries is immaterial)
-    int cnt[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) cnt[c] = 0;
-    for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
-      const int gi = g0 + lane;
-      const int cls = gi < a.nblocks ? 15 - min(15, (int)((float)ord_cost[gi] * to_class)) : -1;
-      if (gi < a.nblocks) ord_cost[gi] = cls;  // the class replaces the cost
-#pragma unroll
-      for (int c = 0; c < 16; ++c) cnt[c] += __popcll(__ballot(cls == c));
-    }
-    int pos[16];
-    {
-      int run = 0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        pos[c] = run;
-        run += cnt[c];
-      }
-    }
     const unsigned long long lt = (1ull << lane) - 1ull;
+    wsync();
     for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
       const int gi = g0 + lane;
-      const int cls = gi < a.nblocks ? ord_cost[gi] : -1;
-      int dst = 0;
-#pragma unroll
+      const bool valid = gi < a.nblocks;
+      const int cls = valid ? 15 - min(15, (int)((float)ord_cost[gi] * to_class)) : 0;
+      if (valid) ord_cost[gi] = cls;  // the class replaces the cost
+      const unsigned long long m = same_class(cls, valid);
+      if (valid && (m & lt) == 0) ord_cnt[cls] += __popcll(m);  // the class's lowest lane
+      wsync();
+    }
+    if (lane == 0) {
+      int run = 0;
       for (int c = 0; c < 16; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (cls == c) dst = pos[c] + __popcll(m & lt);
-        pos[c] += __popcll(m);
+        ord_pos[c] = run;
+        run += ord_cnt[c];
       }
-      if (gi < a.nblocks) a.grp_order[dst] = gi;  // within a class: ascending group index (deterministic, though nothing depends on it)
+    }
+    wsync();
+    for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
+      const int gi = g0 + lane;
+      const bool valid = gi < a.nblocks;
+      const int cls = valid ? ord_cost[gi] : 0;
+      const unsigned long long m = same_class(cls, valid);
+      const int base = ord_pos[cls];
+      if (valid) a.grp_order[base + __popcll(m & lt)] = gi;  // within a class: ascending group index
+      wsync();
+      if (valid && (m & lt) == 0) ord_pos[cls] = base + __popcll(m);
+      wsync();
     }
     if (lane == 0) st->order_valid = 1;
+    if (a.dbg_stamps && lane == 0) a.dbg_stamps[7] = __builtin_amdgcn_s_memtime() - t_ord;
   }
   if (wave != 0) return;
   if (a.mode == 2) {  // compute_error hook
