@@ -797,13 +797,13 @@ __global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a)
 __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
 // --- the solver ----------------------------------------------------------------------------------
-constexpr int kMaxOrderGroups = 8192;  // launch-order sort: groups whose costs fit the solver's LDS
+constexpr int kMaxOrderGroups = 4096;  // launch-order sort: groups whose costs fit the solver's LDS and one load round (8 per thread)
 constexpr int kSolveThreads = 512;  // 8 waves = 2 per SIMD: the serial lane keeps a 256-VGPR budget, the reduction gets 512 loaders
 constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (thread = 16 slot pairs x 32 group subsets)
 #ifndef NGICP_SOLVE_CHUNK
-#define NGICP_SOLVE_CHUNK 48
+#define NGICP_SOLVE_CHUNK 40
 #endif
-constexpr int kSolveChunk = NGICP_SOLVE_CHUNK;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 48 = 1536 groups
+constexpr int kSolveChunk = NGICP_SOLVE_CHUNK;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 40 = 1280 groups
 
 struct SolveArgs {
   LmState* st;
@@ -953,51 +953,71 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   do {                                                                               \
     if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
-  if (a.dbg_stamps && threadIdx.x == 0 && !st->hot.done) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
+  const int done_at_entry = st->hot.done;
+  if (a.dbg_stamps && threadIdx.x == 0 && !done_at_entry) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
   // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
   //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
-  //      covers 1536 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
-  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass.
-  //      The first step's loads are issued BEFORE anything else, so that the staging loads below (state image, group costs)
-  //      share their round trip instead of preceding it. ----
+  //      covers 1280 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
+  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass. ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
   const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
+  // Everything the block needs from memory is requested HERE, before the first wait: the state image the serial lane will work on
+  // (fetched by the whole block, one coalesced access, instead of by lane 0 after the reduction), the first step of group rows, the
+  // groups' measured costs.  Consumed one after the other they were three dependent round trips of ~0.9 us each.
+  __shared__ LmHot L;
+  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
+  constexpr int kHotWords = (int)(sizeof(LmHot) / 4), kHotPerThread = (kHotWords + kSolveThreads - 1) / kSolveThreads;
+  constexpr int kCostPerThread = kMaxOrderGroups / kSolveThreads;
+  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
+  int hv[kHotPerThread];
+#pragma unroll
+  for (int k = 0; k < kHotPerThread; ++k) {
+    const int w = threadIdx.x + k * kSolveThreads;
+    hv[k] = w < kHotWords ? reinterpret_cast<const int*>(&st->hot)[w] : 0;
+  }
+  // (One CU moves 64 B per clock: the 222 KB of 866 rows are ~3.5k cycles on top of the latency.  Rows beyond the grid are skipped by
+  // a branch each: fetching a stand-in row instead - branch-free issue - measured slower, the stand-ins pile up on one channel.)
+  const int last_row = a.nblocks - 1;
   double2 p[kSolveChunk];
 #pragma unroll
   for (int j = 0; j < kSolveChunk; ++j) {
     const int gi = sb + j * kSolveSubs;
-    p[j] = gi < a.nblocks ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
+    p[j] = gi <= last_row ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
   }
-  if (a.mode == 0 && st->hot.done) return;  // (checked behind the loads above: its own round trip overlaps theirs)
-  // The state the serial lane will work on: fetched by the whole block (one coalesced round trip) instead of by lane 0 after
-  // the reduction, where it would be a dependent round trip on the critical path.  The serial lane then works on this LDS
-  // image in place (a register-resident copy needs ~260 VGPRs: it spills at two waves per SIMD), and wave 0 stores it back
-  // with one coalesced pass.
-  __shared__ LmHot L;
-  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
-  {
-    int hv[(sizeof(LmHot) / 4 + kSolveThreads - 1) / kSolveThreads];
-    int k = 0;
-    for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) hv[k++] = reinterpret_cast<const int*>(&st->hot)[w];
-    k = 0;
-    for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += kSolveThreads) reinterpret_cast<int*>(&L)[w] = hv[k++];
-  }
-  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
-  if (order_it)  // the groups' measured costs, for the launch order built further down (visible after the barriers below)
-    for (int gi = threadIdx.x; gi < a.nblocks; gi += kSolveThreads) ord_cost[gi] = a.grp_cost[gi];
-  {
-    double a0 = 0.0, a1 = 0.0;
+  int oc[kCostPerThread];
 #pragma unroll
-    for (int j = 0; j < kSolveChunk; ++j) {
+  for (int k = 0; k < kCostPerThread; ++k) {
+    const int gi = threadIdx.x + k * kSolveThreads;
+    oc[k] = (order_it && gi <= last_row) ? a.grp_cost[gi] : 0;
+  }
+  if (a.mode == 0 && done_at_entry) return;  // (a scalar load issued at the top: it does not wait for the vector loads above)
+  // The serial lane works on the LDS image of the state in place (a register-resident copy needs ~260 VGPRs: it spills at two
+  // waves per SIMD), and wave 0 stores it back with one coalesced pass.
+#pragma unroll
+  for (int k = 0; k < kHotPerThread; ++k) {
+    const int w = threadIdx.x + k * kSolveThreads;
+    if (w < kHotWords) reinterpret_cast<int*>(&L)[w] = hv[k];
+  }
+  if (order_it) {  // the groups' costs, for the launch order built further down (visible after the barriers below)
+#pragma unroll
+    for (int k = 0; k < kCostPerThread; ++k) {
+      const int gi = threadIdx.x + k * kSolveThreads;
+      if (gi < a.nblocks) ord_cost[gi] = oc[k];
+    }
+  }
+  {
+    double a0 = p[0].x, a1 = p[0].y;  // (not 0.0 + p[0]: the compiler places that add, and a wait for the first load alone, before the other loads)
+#pragma unroll
+    for (int j = 1; j < kSolveChunk; ++j) {
       a0 += p[j].x;
       a1 += p[j].y;
     }
-    for (int g0 = sb + kSolveSubs * kSolveChunk; g0 < a.nblocks; g0 += kSolveSubs * kSolveChunk) {  // larger grids: further steps
+    for (int g0 = sb + kSolveSubs * kSolveChunk; g0 <= last_row; g0 += kSolveSubs * kSolveChunk) {  // larger grids: further steps
 #pragma unroll
       for (int j = 0; j < kSolveChunk; ++j) {
         const int gi = g0 + j * kSolveSubs;
-        p[j] = gi < a.nblocks ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
+        p[j] = gi <= last_row ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int j = 0; j < kSolveChunk; ++j) {
