@@ -265,7 +265,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
-  DevBuf dbg, dbg_q, dbg_s, grp_order, grp_cost, batch_far;
+  DevBuf dbg, dbg_q, dbg_s, dbg_span, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
   DevBuf tpt[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
@@ -691,6 +691,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.mode = 3;
   a.dbg_stamps = nullptr;
   a.dbg_qstats = nullptr;
+  a.dbg_span = nullptr;
   {
     // rings worth staging: enough to cover the distance gate (the search never looks farther), at most kStageMaxGrow
     int need = kStageMaxGrow;
@@ -824,6 +825,12 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     HIP_TRY(hipMemsetAsync(h->dbg_s.p, 0, 8 * sizeof(unsigned long long), h->stream));
     c.sa.dbg_stamps = h->dbg_s.as<unsigned long long>();
   }
+  const char* span_path = std::getenv("NGICP_DEBUG_SPAN");  // diagnostic only: when and where every block of the last pass ran
+  if (span_path) {
+    h->dbg_span.ensure((size_t)c.nblocks * 4 * sizeof(unsigned long long));
+    HIP_TRY(hipMemsetAsync(h->dbg_span.p, 0, (size_t)c.nblocks * 4 * sizeof(unsigned long long), h->stream));
+    c.pa.dbg_span = h->dbg_span.as<unsigned long long>();
+  }
   const char* qstat_path = std::getenv("NGICP_DEBUG_QSTATS");  // diagnostic only: per-query search statistics of the last pass
   if (qstat_path) {
     h->dbg_q.ensure((size_t)c.pa.n_src * sizeof(int4));
@@ -879,6 +886,26 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     HIP_TRY(hipMemcpy(ts, h->dbg_s.p, sizeof(ts), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "k_lm_solve stamps (cycles since entry): loads issued %llu, reduced %llu, state in registers %llu, lm_advance %llu, accept path %llu, stored %llu; launch-order section (wave 1) %llu cycles\n",
                  ts[1] - ts[0], ts[2] - ts[0], ts[3] - ts[0], ts[4] - ts[0], ts[5] - ts[0], ts[6] - ts[0], ts[7]);
+  }
+  if (span_path) {
+    std::vector<unsigned long long> hs((size_t)c.nblocks * 4);
+    HIP_TRY(hipMemcpy(hs.data(), h->dbg_span.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(span_path, "wb")) {
+      std::fwrite(hs.data(), sizeof(unsigned long long), hs.size(), f);
+      std::fclose(f);
+    }
+  }
+  if (const char* cost_path = std::getenv("NGICP_DEBUG_COSTS")) {  // diagnostic only: the groups' durations in the last pass (cycles >> 4), the launch order, the partial rows
+    std::vector<int> hc((size_t)c.nblocks * 2);
+    HIP_TRY(hipMemcpy(hc.data(), h->grp_cost.p, (size_t)c.nblocks * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hc.data() + c.nblocks, h->grp_order.p, (size_t)c.nblocks * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<double> hp((size_t)c.nblocks * kNumSlots);
+    HIP_TRY(hipMemcpy(hp.data(), h->partials.p, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(cost_path, "wb")) {
+      std::fwrite(hc.data(), sizeof(int), hc.size(), f);
+      std::fwrite(hp.data(), sizeof(double), hp.size(), f);
+      std::fclose(f);
+    }
   }
   if (qstat_path) {
     std::vector<int> hq((size_t)c.pa.n_src * 4);

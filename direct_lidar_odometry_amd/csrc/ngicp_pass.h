@@ -97,6 +97,7 @@ struct PassArgs {
   int stage_grow;           // rings around the batch box that the LDS row list covers (0: no list, search unindexed)
   unsigned long long* dbg_stamps;  // diagnostic only: [wave][kStampStride] s_memtime stamps + counters, or null
   int4* dbg_qstats;                // diagnostic only: per query {ring-1 candidates, ring-1 walks | far walks << 16, far + shell candidates, flags}, or null
+  unsigned long long* dbg_span;    // diagnostic only: per block {s_memrealtime (10 ns ticks) at entry, at exit, HW_ID | XCC_ID << 32, group}, or null
 };
 
 // --- cooperative exact 1-NN ------------------------------------------------------------------
@@ -342,6 +343,7 @@ __global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a)
   // deep, and the slowest groups take 2-3x the median: started late they would set the kernel's length).
   const int group = (a.grp_order && st->order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
   const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (a.dbg_span && threadIdx.x == 0) a.dbg_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();  // (the 100 MHz counter: the same on every CU)
   for (int item = group * 4 + wave; item < a.n_batches; item = a.n_batches) {
     const int2 it = a.batches[item];
     const int qbase = it.x, qcount = it.y, batch = item;
@@ -788,6 +790,12 @@ __global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a)
   if (threadIdx.x < kNumSlots) {
     const int v = threadIdx.x;
     a.partials[(size_t)group * kNumSlots + v] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
+  }
+  if (a.dbg_span && threadIdx.x == 0) {
+    unsigned long long* d = a.dbg_span + (size_t)blockIdx.x * 4;
+    d[1] = __builtin_amdgcn_s_memrealtime();
+    d[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
+    d[3] = (unsigned long long)(unsigned int)group;
   }
   if (a.grp_cost && threadIdx.x == 0) a.grp_cost[group] = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
 }
