@@ -554,7 +554,7 @@ void ensure_slot_ready(ngicp* h, Slot& s, const char* what) {
 // ------------------------------------------------------------------------------------------
 template <int K>
 void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out) {
-  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + 127) / 128)), dim3(128), 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k,
+  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + kKnnPairs - 1) / kKnnPairs)), dim3(kKnnBlock), 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k,
                      reg, out);
 }
 
@@ -1361,7 +1361,7 @@ int ngicp_target_knn(ngicp_t* h, const float* q, size_t nq, size_t stride, int k
     h->knn_idx.ensure(nq * k * sizeof(int));
     h->knn_d2.ensure(nq * k * sizeof(float));
     HIP_TRY(hipMemcpyAsync(h->queries.p, packed.data(), nq * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-    const dim3 grid((unsigned)((nq + 127) / 128)), block(128);
+    const dim3 grid((unsigned)((nq + kKnnPairs - 1) / kKnnPairs)), block(kKnnBlock);  // a pair of lanes per query
     if (k <= 10)
       hipLaunchKernelGGL(k_knn_queries<10>, grid, block, 0, h->stream, T.pts(), T.cells(), T.grid, h->queries.as<float4>(), (int)nq, k,
                          h->knn_idx.as<int>(), h->knn_d2.as<float>());

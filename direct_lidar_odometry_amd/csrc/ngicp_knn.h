@@ -41,15 +41,16 @@ struct TopK {
   }
   __device__ __forceinline__ float last_d() const { return d_; }
   __device__ __forceinline__ int last_id() const { return id_; }
-  // insert (dist, index) given dist < d[kth]; elements equal to dist stay in front (strict '>')
-  __device__ __forceinline__ void insert(float dist, int index) {
+  // insert (dist, index) behind the entries <= key (strict '>': entries equal to the key stay in front); an entry that does not
+  // beat the last one changes nothing.  key == dist is the ordinary insert; key < 0 puts the entry in front of everything.
+  __device__ __forceinline__ void insert(float key, float dist, int index) {
     const float pd = head.last_d();  // slot K-2 before it moves
     const int pi = head.last_id();
-    const bool shift = pd > dist;
-    const bool here = !shift && (d_ > dist);
+    const bool shift = pd > key;
+    const bool here = !shift && (d_ > key);
     d_ = shift ? pd : (here ? dist : d_);
     id_ = shift ? pi : (here ? index : id_);
-    head.insert(dist, index);
+    head.insert(key, dist, index);
   }
   __device__ __forceinline__ float d_at(int s) const { return s == K - 1 ? d_ : head.d_at(s); }  // run-time slot: a select chain
   __device__ __forceinline__ float kth(int k) const { return d_at(k - 1); }
@@ -72,8 +73,8 @@ struct TopK<1> {
   }
   __device__ __forceinline__ float last_d() const { return d_; }
   __device__ __forceinline__ int last_id() const { return id_; }
-  __device__ __forceinline__ void insert(float dist, int index) {
-    if (d_ > dist) {
+  __device__ __forceinline__ void insert(float key, float dist, int index) {
+    if (d_ > key) {
       d_ = dist;
       id_ = index;
     }
@@ -107,81 +108,124 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const floa
 // Every position is visited at most once (no duplicates in the list).  Ties: the first visited stays in front (strict '<'), like
 // KNNResultSet::addPoint (impl/nanoflann_impl.hpp:184-211); the visiting order is not a kd-tree's, so among EXACTLY equal
 // distances another index may be kept (SURVEY.md §7 "Ties").
-// The eight points of a window (positions w .. w+7; `valid`: which of them belong to the run) against the list.  A candidate is
-// inserted by a K-step predicated shift that the WHOLE wave executes whenever any lane inserts; taking the eight positions in turn
-// would run it eight times per window although a lane typically has 0-3 candidates that beat its k-th best, so each lane first
-// marks its passing candidates and the wave loops over the lanes' marks: as many insert rounds as the busiest lane needs.
-// Candidates are still taken in increasing position (first visited stays in front among equal distances).
+//
+// TWO LANES PER QUERY (a pair: lanes 2i, 2i + 1; `sub` = lane & 1).  A thread per query left a 100k-point scan at 38 % of the
+// chip's wave slots with every wave on its own dependency chain; a pair halves the chain instead of doubling the candidates:
+//   * ONE sorted list per pair, slots 0..K/2-1 in lane 0, K/2..K-1 in lane 1.  An insert is a K/2-step predicated shift that
+//     both lanes run at once: lane 0 shifts the candidate into its half and hands what falls off its end (or the candidate itself,
+//     if it belongs behind) to lane 1 - the list, the k-th best and the tie order are exactly those of a single K-slot list;
+//   * a window's eight points are fetched and distance-tested four per lane; passing candidates are marked per lane and taken in
+//     increasing position (lane 0's marks, then lane 1's), each broadcast to the pair by a shuffle.
+// Both lanes of a pair hold the same query and the same `worst`, so every branch below is uniform inside a pair.
 template <int K>
-__device__ __forceinline__ void knn_take_window(const float4 (&c)[8], int w, unsigned int valid, float qx, float qy, float qz, int k, TopK<K>& top, float& worst) {
-  float d[8];
+struct PairTopK {
+  static_assert(K % 2 == 0, "the list is split evenly over the two lanes of a pair");
+  static constexpr int H = K / 2;
+  TopK<H> part;  // slots sub * H .. sub * H + H - 1
+  __device__ __forceinline__ void init() { part.init(); }
+  // both lanes call with the same candidate
+  __device__ __forceinline__ void insert(float dist, int index, int sub, int lane) {
+    // what moves on to the upper half: the lower half's last entry if the candidate goes in front of it, else the candidate
+    const float ld = part.last_d();
+    const int li = part.last_id();
+    const bool low = ld > dist;
+    const float cd = __shfl(low ? ld : dist, lane & ~1);
+    const int ci = __shfl(low ? li : index, lane & ~1);
+    const float ck = __shfl(low ? -1.f : dist, lane & ~1);  // the lower half's old last entry stays in front of the upper half's entries
+    part.insert(sub ? ck : dist, sub ? cd : dist, sub ? ci : index);  // (an entry that does not beat the half's last one changes nothing)
+  }
+  __device__ __forceinline__ float kth(int k, int sub, int lane) const {  // the same in both lanes
+    const int slot = k - 1;
+    return __shfl(part.d_at(slot >= H ? slot - H : slot), (lane & ~1) | (slot >= H ? 1 : 0));
+  }
+};
+
+// The lane's four points of a window (positions w + 4 sub .. w + 4 sub + 3; `valid`: which of the window's eight belong to the run).
+template <int K>
+__device__ __forceinline__ void knn_take_window(const float4 (&c)[4], int w, unsigned int valid, float qx, float qy, float qz, int k, PairTopK<K>& top, float& worst,
+                                                int sub, int lane) {
+  float d[4];
   unsigned int mask = 0;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 4; ++j) {
     d[j] = sqdist(qx, qy, qz, c[j]);
-    if (((valid >> j) & 1u) && d[j] < worst) mask |= 1u << j;
+    if (((valid >> (4 * sub + j)) & 1u) && d[j] < worst) mask |= 1u << j;
   }
-  while (mask) {
-    const int j = __ffs((int)mask) - 1;
-    mask &= mask - 1;
-    float dj = d[0];
 #pragma unroll
-    for (int t = 1; t < 8; ++t) dj = (j == t) ? d[t] : dj;
-    if (dj < worst) {  // (the bound may have tightened since the candidate was marked)
-      top.insert(dj, w + j);
-      worst = fminf(worst, top.kth(k));
+  for (int owner = 0; owner < 2; ++owner) {
+    unsigned int m = __shfl(mask, (lane & ~1) | owner);  // (uniform in the pair)
+    while (m) {
+      const int j = __ffs((int)m) - 1;
+      m &= m - 1;
+      float dj = d[0];
+#pragma unroll
+      for (int t = 1; t < 4; ++t) dj = (j == t) ? d[t] : dj;
+      dj = __shfl(dj, (lane & ~1) | owner);
+      if (dj < worst) {  // (the bound may have tightened since the candidate was marked)
+        top.insert(dj, w + 4 * owner + j, sub, lane);
+        worst = fminf(worst, top.kth(k, sub, lane));
+      }
     }
   }
 }
 
 template <int K>
-__device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, int s, int e, int m, float qx, float qy, float qz, float gap, int k, TopK<K>& top,
-                                             float& worst) {
+__device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, int s, int e, int m, float qx, float qy, float qz, float gap, int k, PairTopK<K>& top,
+                                             float& worst, int sub, int lane) {
   m = min(max(m, s), e - 1);
   for (int w = m; w < e; w += 8) {  // [m, e)
-    float4 c[8];
+    float4 c[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = sorted[min(w + j, e - 1)];
-    knn_take_window<K>(c, w, w + 8 <= e ? 0xffu : (0xffu >> (w + 8 - e)), qx, qy, qz, k, top, worst);
-    const float dr = c[7].x - qx;  // the window's (or the run's) last point: everything beyond has a larger x
+    for (int j = 0; j < 4; ++j) c[j] = sorted[min(w + 4 * sub + j, e - 1)];
+    knn_take_window<K>(c, w, w + 8 <= e ? 0xffu : (0xffu >> (w + 8 - e)), qx, qy, qz, k, top, worst, sub, lane);
+    const float dr = __shfl(c[3].x, lane | 1) - qx;  // the window's (or the run's) last point: everything beyond has a larger x
     if (dr > 0.f && dr * dr + gap > worst) break;
   }
   for (int w = m - 8; w + 8 > s; w -= 8) {  // [s, m), nearest window first
-    float4 c[8];
+    float4 c[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = sorted[max(w + j, s)];
-    knn_take_window<K>(c, w, w >= s ? 0xffu : ((0xffu << (s - w)) & 0xffu), qx, qy, qz, k, top, worst);
-    const float dl = qx - c[0].x;
+    for (int j = 0; j < 4; ++j) c[j] = sorted[max(w + 4 * sub + j, s)];
+    knn_take_window<K>(c, w, w >= s ? 0xffu : ((0xffu << (s - w)) & 0xffu), qx, qy, qz, k, top, worst, sub, lane);
+    const float dl = qx - __shfl(c[0].x, lane & ~1);
     if (dl > 0.f && dl * dl + gap > worst) break;
   }
 }
 
-constexpr int kKnnBlock = 128;  // threads per block of the k-NN kernels (each thread parks 36 row bounds in LDS)
+constexpr int kKnnBlock = 128;             // threads per block of the k-NN kernels
+constexpr int kKnnPairs = kKnnBlock / 2;   // queries per block (each pair parks 36 row bounds in LDS)
 
 template <int K>
 __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
-                                           int p, int k, TopK<K>& top, int* __restrict__ lds_bounds /* [36][kKnnBlock], this thread's column */) {
+                                           int p, int k, PairTopK<K>& top, int* __restrict__ lds_bounds /* [36][kKnnPairs], this pair's column */, int sub, int lane) {
   top.init();
   float worst = 3.4028234664e38f;
   int cx, cy, cz;
   cell_coords(g, qx, qy, qz, cx, cy, cz);
   // ---- rings 0..1: the bounds of all nine rows of the 3 x 3 window are fetched in ONE round trip (one 16-byte load per row gives
-  //      the starts of the cells cx-1, cx, cx+1, cx+2: the cell-start table is padded for it); the query's own row is walked
-  //      first, from the query itself when it is a point of this cloud, else from where qx sits inside its own cell ----
+  //      the starts of the cells cx-1, cx, cx+1, cx+2: the cell-start table is padded for it; lane 0 fetches rows 0..4, lane 1 rows
+  //      5..8) and parked in LDS; the query's own row is walked first, from the query itself when it is a point of this cloud, else
+  //      from where qx sits inside its own cell ----
   {
     struct alignas(4) Bounds4 { int v[4]; };
     {
-      Bounds4 bnd[9];  // all nine loads in flight, then parked in LDS (indexed by a run-time row below: registers would spill)
+      Bounds4 bnd[5];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int u = 0; u < 5; ++u) {
+        const int t = min(5 * sub + u, 8);
         const int y = min(max(cy + t % 3 - 1, 0), g.ny - 1), z = min(max(cz + t / 3 - 1, 0), g.nz - 1);  // (rows outside the grid are skipped below)
-        bnd[t] = *reinterpret_cast<const Bounds4*>(cell_start + ((z * g.ny + y) * g.nx + cx - 1));
+        bnd[u] = *reinterpret_cast<const Bounds4*>(cell_start + ((z * g.ny + y) * g.nx + cx - 1));
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int u = 0; u < 5; ++u) {
+        const int t = 5 * sub + u;
+        if (t < 9)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) lds_bounds[(t * 4 + v) * kKnnBlock] = bnd[t].v[v];
+          for (int v = 0; v < 4; ++v) lds_bounds[(t * 4 + v) * kKnnPairs] = bnd[u].v[v];
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the pair's other lane reads what this one parked)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
     for (int o = 0; o < 9; ++o) {
       const int t = o == 0 ? 4 : (o <= 4 ? o - 1 : o);  // the own row first
@@ -189,12 +233,12 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
       if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
       const float gap = t == 4 ? 0.f : row_gap_sq(g, y, z, cy, cz, qy, qz);
       if (gap >= worst) continue;
-      const int v0 = lds_bounds[(t * 4 + 0) * kKnnBlock], v1 = lds_bounds[(t * 4 + 1) * kKnnBlock], v2 = lds_bounds[(t * 4 + 2) * kKnnBlock],
-                v3 = lds_bounds[(t * 4 + 3) * kKnnBlock];
+      const int v0 = lds_bounds[(t * 4 + 0) * kKnnPairs], v1 = lds_bounds[(t * 4 + 1) * kKnnPairs], v2 = lds_bounds[(t * 4 + 2) * kKnnPairs],
+                v3 = lds_bounds[(t * 4 + 3) * kKnnPairs];
       const int s = cx > 0 ? v0 : v1, e = cx < g.nx - 1 ? v3 : v2;
       if (e <= s) continue;
       const int m = (t == 4 && p >= 0) ? p : v1 + (int)(fx * (float)(v2 - v1));
-      knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst);
+      knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst, sub, lane);
     }
   }
   // ---- rings 2, 3, ... while the k-th best is not provably exact: the rows on the frame of the (2r+1)^2 window (runs cx-r..cx+r)
@@ -229,7 +273,7 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
         const int s = cell_start[row + c0], e = cell_start[row + c1 + 1];
         if (e <= s) continue;
         const int m = m_hint == 1 ? e - 1 : (m_hint == 2 ? s : s + (int)(frac * (float)(e - s)));
-        knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst);
+        knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst, sub, lane);
       }
     }
   }
@@ -244,35 +288,62 @@ enum { REG_NONE = 0, REG_MIN_EIG = 1, REG_NORMALIZED_MIN_EIG = 2, REG_PLANE = 3,
 template <int K>
 __global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int n, int k, int reg,
                                                             double* __restrict__ covs6) {
-  __shared__ int lds_bounds[36 * kKnnBlock];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int lds_bounds[36 * kKnnPairs];
+  constexpr int H = K / 2;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & 1, pair = threadIdx.x >> 1;
+  const int i = blockIdx.x * kKnnPairs + pair;  // a pair of lanes per point
   if (i >= n) return;
   const float4 q = sorted[i];
-  TopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top, lds_bounds + threadIdx.x);
+  PairTopK<K> top;
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top, lds_bounds + pair, sub, lane);
 
-  // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k
+  // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k.  The neighbours are added in list order:
+  // lane 0 adds its slots 0..K/2-1, lane 1 takes the sums over and continues with K/2..k-1 (the association of a single thread).
+  float4 nb[H];
+  static_for<0, H>([&](auto S) {
+    const int id = top.part.template id<S.value>();
+    nb[S.value] = (sub * H + S.value < k && id >= 0) ? sorted[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  });
   double mx = 0, my = 0, mz = 0;
-  static_for<0, K>([&](auto S) {
-    if (S.value < k) {
-      const float4 p = sorted[top.template id<S.value>()];
-      mx += (double)p.x;
-      my += (double)p.y;
-      mz += (double)p.z;
-    }
-  });
-  mx = mx / (double)k;
-  my = my / (double)k;
-  mz = mz / (double)k;
+  if (sub == 0) {
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+      if (j < k) {
+        mx += (double)nb[j].x;
+        my += (double)nb[j].y;
+        mz += (double)nb[j].z;
+      }
+  }
+  mx = __shfl(mx, lane & ~1);
+  my = __shfl(my, lane & ~1);
+  mz = __shfl(mz, lane & ~1);
+  if (sub == 1) {
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+      if (H + j < k) {
+        mx += (double)nb[j].x;
+        my += (double)nb[j].y;
+        mz += (double)nb[j].z;
+      }
+  }
+  mx = __shfl(mx, lane | 1) / (double)k;
+  my = __shfl(my, lane | 1) / (double)k;
+  mz = __shfl(mz, lane | 1) / (double)k;
   double C[6] = {0, 0, 0, 0, 0, 0};
-  static_for<0, K>([&](auto S) {
-    if (S.value < k) {
-      const float4 p = sorted[top.template id<S.value>()];
-      const double x = (double)p.x - mx, y = (double)p.y - my, z = (double)p.z - mz;
-      C[0] += x * x; C[1] += x * y; C[2] += x * z;
-      C[3] += y * y; C[4] += y * z; C[5] += z * z;
-    }
-  });
+  auto add_centred = [&](int first) {
+#pragma unroll
+    for (int j = 0; j < H; ++j)
+      if (first + j < k) {
+        const double x = (double)nb[j].x - mx, y = (double)nb[j].y - my, z = (double)nb[j].z - mz;
+        C[0] += x * x; C[1] += x * y; C[2] += x * z;
+        C[3] += y * y; C[4] += y * z; C[5] += z * z;
+      }
+  };
+  if (sub == 0) add_centred(0);
+#pragma unroll
+  for (int e = 0; e < 6; ++e) C[e] = __shfl(C[e], lane & ~1);
+  if (sub == 0) return;  // lane 1 finishes the point
+  add_centred(H);
 #pragma unroll
   for (int e = 0; e < 6; ++e) C[e] = C[e] / (double)k;
 
@@ -323,17 +394,20 @@ __global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restr
 template <int K>
 __global__ void __launch_bounds__(kKnnBlock) k_knn_queries(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, const float4* __restrict__ queries,
                                                       int nq, int k, int* __restrict__ out_idx, float* __restrict__ out_d2) {
-  __shared__ int lds_bounds[36 * kKnnBlock];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int lds_bounds[36 * kKnnPairs];
+  constexpr int H = K / 2;
+  const int lane = threadIdx.x & 63, sub = threadIdx.x & 1, pair = threadIdx.x >> 1;
+  const int i = blockIdx.x * kKnnPairs + pair;
   if (i >= nq) return;
   const float4 q = queries[i];
-  TopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top, lds_bounds + threadIdx.x);
-  static_for<0, K>([&](auto S) {
-    if (S.value < k) {
-      const int pos = top.template id<S.value>();
-      out_idx[(size_t)i * k + S.value] = pos >= 0 ? __float_as_int(sorted[pos].w) : -1;
-      out_d2[(size_t)i * k + S.value] = pos >= 0 ? top.template d<S.value>() : __builtin_inff();
+  PairTopK<K> top;
+  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top, lds_bounds + pair, sub, lane);
+  static_for<0, H>([&](auto S) {
+    const int slot = sub * H + S.value;
+    if (slot < k) {
+      const int pos = top.part.template id<S.value>();
+      out_idx[(size_t)i * k + slot] = pos >= 0 ? __float_as_int(sorted[pos].w) : -1;
+      out_d2[(size_t)i * k + slot] = pos >= 0 ? top.part.template d<S.value>() : __builtin_inff();
     }
   });
 }
