@@ -554,8 +554,13 @@ void ensure_slot_ready(ngicp* h, Slot& s, const char* what) {
 // ------------------------------------------------------------------------------------------
 template <int K>
 void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out) {
-  hipLaunchKernelGGL(k_covariances<K>, dim3((unsigned)((dc.n + kKnnPairs - 1) / kKnnPairs)), dim3(kKnnBlock), 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k,
-                     reg, out);
+  const dim3 grid((unsigned)((dc.n + kKnnPairs - 1) / kKnnPairs)), block(kKnnBlock);
+  // window size by cloud size (see knn_take_window): a scan that does not fill the chip is as slow as one wave's chain of round
+  // trips - wider windows; a large cloud is bound by what its waves fetch and insert - narrow ones
+  if (dc.n < 160000)
+    hipLaunchKernelGGL((k_covariances<K, 6>), grid, block, 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k, reg, out);
+  else
+    hipLaunchKernelGGL((k_covariances<K, 4>), grid, block, 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k, reg, out);
 }
 
 void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {

@@ -103,7 +103,7 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const floa
 //           cx-r and cx+r.  A row or cell whose gap to the query alone reaches `worst` is skipped without a memory access.
 //           (A list-based bound only exists once the list holds k entries: until then `worst` is FLT_MAX and nothing is pruned.)
 //   walk    a run is walked outward from a starting position (the query point itself when it belongs to the cloud: p >= 0; else
-//           where qx sits in the run, interpolated), eight points per round trip, right then left, each side only while
+//           where qx sits in the run, interpolated), one window per round trip, right then left, each side only while
 //           |dx|^2 + gap can still beat `worst`.
 // Every position is visited at most once (no duplicates in the list).  Ties: the first visited stays in front (strict '<'), like
 // KNNResultSet::addPoint (impl/nanoflann_impl.hpp:184-211); the visiting order is not a kd-tree's, so among EXACTLY equal
@@ -140,16 +140,19 @@ struct PairTopK {
   }
 };
 
-// The lane's four points of a window (positions w + 4 sub .. w + 4 sub + 3; `valid`: which of the window's eight belong to the run).
-template <int K>
-__device__ __forceinline__ void knn_take_window(const float4 (&c)[4], int w, unsigned int valid, float qx, float qy, float qz, int k, PairTopK<K>& top, float& worst,
+// WL = points of a window per lane (a window = 2 WL points = one round trip of the pair).  Measured (k = 20): 4 is best when the
+// launch fills the chip (250k OS1 points: 0.249 ms against 0.283 / 0.299 ms with 6 / 8), 6 when it does not and a wave's chain of
+// round trips is what counts (100k-point VLP-16 scan, 61 % of the wave slots: 0.119 against 0.128 ms); the host picks by cloud size.
+// The lane's points of a window (positions w + WL sub ...; `valid`: which of the window's points belong to the run).
+template <int K, int WL>
+__device__ __forceinline__ void knn_take_window(const float4 (&c)[WL], int w, unsigned int valid, float qx, float qy, float qz, int k, PairTopK<K>& top, float& worst,
                                                 int sub, int lane) {
-  float d[4];
+  float d[WL];
   unsigned int mask = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < WL; ++j) {
     d[j] = sqdist(qx, qy, qz, c[j]);
-    if (((valid >> (4 * sub + j)) & 1u) && d[j] < worst) mask |= 1u << j;
+    if (((valid >> (WL * sub + j)) & 1u) && d[j] < worst) mask |= 1u << j;
   }
 #pragma unroll
   for (int owner = 0; owner < 2; ++owner) {
@@ -159,33 +162,35 @@ __device__ __forceinline__ void knn_take_window(const float4 (&c)[4], int w, uns
       m &= m - 1;
       float dj = d[0];
 #pragma unroll
-      for (int t = 1; t < 4; ++t) dj = (j == t) ? d[t] : dj;
+      for (int t = 1; t < WL; ++t) dj = (j == t) ? d[t] : dj;
       dj = __shfl(dj, (lane & ~1) | owner);
       if (dj < worst) {  // (the bound may have tightened since the candidate was marked)
-        top.insert(dj, w + 4 * owner + j, sub, lane);
+        top.insert(dj, w + WL * owner + j, sub, lane);
         worst = fminf(worst, top.kth(k, sub, lane));
       }
     }
   }
 }
 
-template <int K>
+template <int K, int WL>
 __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, int s, int e, int m, float qx, float qy, float qz, float gap, int k, PairTopK<K>& top,
                                              float& worst, int sub, int lane) {
+  constexpr int kKnnW = 2 * WL;
+  constexpr unsigned int kAll = (1u << kKnnW) - 1u;
   m = min(max(m, s), e - 1);
-  for (int w = m; w < e; w += 8) {  // [m, e)
-    float4 c[4];
+  for (int w = m; w < e; w += kKnnW) {  // [m, e)
+    float4 c[WL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = sorted[min(w + 4 * sub + j, e - 1)];
-    knn_take_window<K>(c, w, w + 8 <= e ? 0xffu : (0xffu >> (w + 8 - e)), qx, qy, qz, k, top, worst, sub, lane);
-    const float dr = __shfl(c[3].x, lane | 1) - qx;  // the window's (or the run's) last point: everything beyond has a larger x
+    for (int j = 0; j < WL; ++j) c[j] = sorted[min(w + WL * sub + j, e - 1)];
+    knn_take_window<K, WL>(c, w, w + kKnnW <= e ? kAll : (kAll >> (w + kKnnW - e)), qx, qy, qz, k, top, worst, sub, lane);
+    const float dr = __shfl(c[WL - 1].x, lane | 1) - qx;  // the window's (or the run's) last point: everything beyond has a larger x
     if (dr > 0.f && dr * dr + gap > worst) break;
   }
-  for (int w = m - 8; w + 8 > s; w -= 8) {  // [s, m), nearest window first
-    float4 c[4];
+  for (int w = m - kKnnW; w + kKnnW > s; w -= kKnnW) {  // [s, m), nearest window first
+    float4 c[WL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = sorted[max(w + 4 * sub + j, s)];
-    knn_take_window<K>(c, w, w >= s ? 0xffu : ((0xffu << (s - w)) & 0xffu), qx, qy, qz, k, top, worst, sub, lane);
+    for (int j = 0; j < WL; ++j) c[j] = sorted[max(w + WL * sub + j, s)];
+    knn_take_window<K, WL>(c, w, w >= s ? kAll : ((kAll << (s - w)) & kAll), qx, qy, qz, k, top, worst, sub, lane);
     const float dl = qx - __shfl(c[0].x, lane & ~1);
     if (dl > 0.f && dl * dl + gap > worst) break;
   }
@@ -194,7 +199,7 @@ __device__ __forceinline__ void knn_walk_row(const float4* __restrict__ sorted, 
 constexpr int kKnnBlock = 128;             // threads per block of the k-NN kernels
 constexpr int kKnnPairs = kKnnBlock / 2;   // queries per block (each pair parks 36 row bounds in LDS)
 
-template <int K>
+template <int K, int WL>
 __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restrict__ sorted, const int* __restrict__ cell_start, float qx, float qy, float qz,
                                            int p, int k, PairTopK<K>& top, int* __restrict__ lds_bounds /* [36][kKnnPairs], this pair's column */, int sub, int lane) {
   top.init();
@@ -238,7 +243,7 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
       const int s = cx > 0 ? v0 : v1, e = cx < g.nx - 1 ? v3 : v2;
       if (e <= s) continue;
       const int m = (t == 4 && p >= 0) ? p : v1 + (int)(fx * (float)(v2 - v1));
-      knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst, sub, lane);
+      knn_walk_row<K, WL>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst, sub, lane);
     }
   }
   // ---- rings 2, 3, ... while the k-th best is not provably exact: the rows on the frame of the (2r+1)^2 window (runs cx-r..cx+r)
@@ -273,7 +278,7 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
         const int s = cell_start[row + c0], e = cell_start[row + c1 + 1];
         if (e <= s) continue;
         const int m = m_hint == 1 ? e - 1 : (m_hint == 2 ? s : s + (int)(frac * (float)(e - s)));
-        knn_walk_row<K>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst, sub, lane);
+        knn_walk_row<K, WL>(sorted, s, e, m, qx, qy, qz, gap, k, top, worst, sub, lane);
       }
     }
   }
@@ -285,7 +290,7 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
 // ---------------------------------------------------------------------------------------------
 enum { REG_NONE = 0, REG_MIN_EIG = 1, REG_NORMALIZED_MIN_EIG = 2, REG_PLANE = 3, REG_FROBENIUS = 4 };
 
-template <int K>
+template <int K, int WL>
 __global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int n, int k, int reg,
                                                             double* __restrict__ covs6) {
   __shared__ int lds_bounds[36 * kKnnPairs];
@@ -295,7 +300,7 @@ __global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restr
   if (i >= n) return;
   const float4 q = sorted[i];
   PairTopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top, lds_bounds + pair, sub, lane);
+  knn_search<K, WL>(g, sorted, cell_start, q.x, q.y, q.z, i, k, top, lds_bounds + pair, sub, lane);
 
   // impl/nano_gicp_impl.hpp:315-321: mean-centre the k neighbours (FP64), C = X X^T / k.  The neighbours are added in list order:
   // lane 0 adds its slots 0..K/2-1, lane 1 takes the sums over and continues with K/2..k-1 (the association of a single thread).
@@ -401,7 +406,7 @@ __global__ void __launch_bounds__(kKnnBlock) k_knn_queries(const float4* __restr
   if (i >= nq) return;
   const float4 q = queries[i];
   PairTopK<K> top;
-  knn_search<K>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top, lds_bounds + pair, sub, lane);
+  knn_search<K, 4>(g, sorted, cell_start, q.x, q.y, q.z, -1, k, top, lds_bounds + pair, sub, lane);
   static_for<0, H>([&](auto S) {
     const int slot = sub * H + S.value;
     if (slot < k) {
