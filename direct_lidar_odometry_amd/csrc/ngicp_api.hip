@@ -265,6 +265,7 @@ struct ngicp {
 
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
+  int pass_slots = 768;  // blocks of the 3-waves-per-SIMD pass kernel resident on this device at once
   DevBuf dbg, dbg_q, dbg_s, dbg_span, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
@@ -634,8 +635,15 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
 // Registration loop
 // ------------------------------------------------------------------------------------------
 void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s) {
-  (void)h;
-  hipLaunchKernelGGL(k_gicp_pass<2>, dim3(nblocks), dim3(256), 0, s, a);  // 32-query batches, 2 lanes per query
+  // 32-query batches, 2 lanes per query.  Two builds of the kernel: 3 waves per SIMD (134 VGPRs), and 4 (128 VGPRs, a few spilled
+  // dwords, 4 blocks per CU) for grids of more than two rounds of blocks, where the launch is bound by how many blocks pass through
+  // the chip rather than by its slowest block.
+  static const int force = std::getenv("NGICP_PASS_WPS") ? std::atoi(std::getenv("NGICP_PASS_WPS")) : 0;  // (A/B timing only)
+  const bool four = force ? force == 4 : nblocks > 2 * h->pass_slots;
+  if (four)
+    hipLaunchKernelGGL((k_gicp_pass<2, 4>), dim3(nblocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_gicp_pass<2, 3>), dim3(nblocks), dim3(256), 0, s, a);
 }
 
 struct LoopCtx {
@@ -1054,6 +1062,12 @@ int ngicp_create(int device, ngicp_t** out) {
     std::memcpy(h->final_T, I, sizeof(I));
     std::memset(h->final_hessian, 0, sizeof(h->final_hessian));
     for (int i = 0; i < 6; ++i) h->final_hessian[i * 6 + i] = 1.0;  // impl/lsq_registration_impl.hpp:62
+    {
+      int cus = 0, per_cu = 0;
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+      HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_pass<2, 3>, 256, 0));
+      h->pass_slots = std::max(1, cus) * std::max(1, per_cu);
+    }
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_CHUNK")) h->chunk_pairs = std::max(1, std::min(64, std::atoi(s)));

@@ -148,8 +148,9 @@ constexpr int kStageXs = 20;         // cells per row of the region
 constexpr int kStageMaxGrow = 6;
 
 #ifndef NGICP_PASS_WAVES
-#define NGICP_PASS_WAVES 3  // waves per SIMD the pass kernel is compiled for.  4 fits (128 VGPRs with 7 spilled dwords, 40 KB LDS per block) and
-                            // was measured: c3 +7 %, c2 +3 %, c5 -3 % in time - twelve waves already saturate a CU's gather path
+#define NGICP_PASS_WAVES 3  // waves per SIMD the pass kernel is compiled for by default.  4 fits (128 VGPRs with 6 spilled dwords, 40 KB LDS per
+                            // block) and was measured: c3 +5 %, c2 +6 %, c5 -5 % in time - twelve waves already saturate a CU's gather path on
+                            // a grid of one round of blocks; the host launches the 4-wave build on grids of more than two rounds
 #endif
 #ifndef NGICP_WALK_WINDOW
 #define NGICP_WALK_WINDOW 12
@@ -302,8 +303,8 @@ constexpr int kStampStride = 24;
     if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * kStampStride + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-template <int G>
-__global__ void __launch_bounds__(256, NGICP_PASS_WAVES) k_gicp_pass(PassArgs a) {
+template <int G, int WPS = NGICP_PASS_WAVES>
+__global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   constexpr int B = 64 / G;  // queries per wave batch
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
