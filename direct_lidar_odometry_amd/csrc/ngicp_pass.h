@@ -955,8 +955,11 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
 __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   __shared__ double wsum[kSolveSubs][kPartialStride];
   __shared__ double sums[kPartialStride];
-  __shared__ int ord_cnt[16], ord_pos[16];
+  __shared__ int ord_cnt[kSolveThreads / 64 - 1][16], ord_pos[kSolveThreads / 64 - 1][16];  // per sorting wave and cost class
   __shared__ int ord_cost[kMaxOrderGroups];
+  __shared__ unsigned char ord_cls[kMaxOrderGroups];
+  __shared__ int ord_arrived;
+  if (threadIdx.x == 0) ord_arrived = 0;  // (visible to every wave after the barriers below)
   LmState* st = a.st;
 #define NG_SSTAMP(k)                                                                 \
   do {                                                                               \
@@ -1050,17 +1053,19 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
   NG_SSTAMP(2);
   if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
   if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
-  // (The order is refreshed after the first two passes of an alignment and then after every fourth: group costs move slowly, and
-  // at 7 us for 866 groups / 17 us for 2170 this section, not the state machine, would otherwise end the kernel.)
-  if (order_it && wave == 1 && (L.passes < 2 || (L.passes & 3) == 1)) {
+  if (order_it && wave >= 1) {
     const unsigned long long t_ord = a.dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    // ---- launch order of the next pass, built by wave 1 (costs already in LDS) while lane 0 runs the state machine:
-    //      16 cost classes relative to the slowest group, heaviest class first.  (The pass's results do not depend on the
-    //      launch order.) ----
-    // A lone wave issues about one instruction per 4-5 cycles, so this section is instruction-bound and sits on the kernel's critical
-    // path at large grids (2170 groups at c5).  No per-lane atomics and no per-class loops: four ballots (one per bit of the class)
-    // give every lane the mask of the lanes that share its class; its rank is a popcount, and the lowest lane of each class moves
-    // the class's counter in LDS (distinct addresses per class: no conflicts; same-wave LDS operations are ordered).
+    // ---- launch order of the next pass, built by waves 1..7 (costs already in LDS) while lane 0 of wave 0 runs the state machine:
+    //      a counting sort into 16 cost classes relative to the slowest group, heaviest class first, ascending group index inside
+    //      a class.  (The pass's results do not depend on the launch order.) ----
+    // A lone wave is bound by the latency of its own LDS round trips (~600 cycles per 64 groups and loop: 7 us for 866 groups, 17 us
+    // for 2217 - longer than the state machine), so every wave sorts a contiguous SLICE of the groups: it counts its slice per class,
+    // the seven waves meet at a counter in LDS (all waves of a block are resident: the wait cannot deadlock, and it is bounded), and
+    // each then knows where its slice starts inside every class.  No per-lane atomics and no per-class loops: four ballots (one per
+    // bit of the class) give every lane the mask of the lanes that share its class; its rank is a popcount, and the lowest lane of
+    // each class moves the class's counter in LDS (distinct addresses per class; same-wave LDS operations are ordered).
+    constexpr int kSortWaves = kSolveThreads / 64 - 1;
+    const int sw = wave - 1;
     auto wsync = [] {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1076,44 +1081,60 @@ __global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
       }
       return m;
     };
-    if (lane < 16) ord_cnt[lane] = 0;
-    int mx = 1;
+    if (lane < 16) ord_cnt[sw][lane] = 0;
+    int mx = 1;  // (every wave looks at all the costs: no exchange needed for the maximum)
     for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, ord_cost[gi]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
     const float to_class = 16.0f / ((float)mx + 1.0f);  // (a heuristic: float rounding at class boundaries is immaterial)
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const int slice = ((a.nblocks + kSortWaves * 64 - 1) / (kSortWaves * 64)) * 64;  // groups per wave, a multiple of 64
+    const int g_first = sw * slice, g_last = min(g_first + slice, a.nblocks);
     wsync();
-    for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
+    for (int g0 = g_first; g0 < g_last; g0 += 64) {
       const int gi = g0 + lane;
-      const bool valid = gi < a.nblocks;
+      const bool valid = gi < g_last;
       const int cls = valid ? 15 - min(15, (int)((float)ord_cost[gi] * to_class)) : 0;
-      if (valid) ord_cost[gi] = cls;  // the class replaces the cost
+      if (valid) ord_cls[gi] = (unsigned char)cls;
       const unsigned long long m = same_class(cls, valid);
-      if (valid && (m & lt) == 0) ord_cnt[cls] += __popcll(m);  // the class's lowest lane
+      if (valid && (m & lt) == 0) ord_cnt[sw][cls] += __popcll(m);  // the class's lowest lane
       wsync();
     }
-    if (lane == 0) {
-      int run = 0;
-      for (int c = 0; c < 16; ++c) {
-        ord_pos[c] = run;
-        run += ord_cnt[c];
+    // the seven waves meet
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&ord_arrived, 1);
+    bool met = false;
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      if (*reinterpret_cast<volatile int*>(&ord_arrived) >= kSortWaves) {
+        met = true;
+        break;
       }
+      __builtin_amdgcn_s_sleep(2);
     }
-    wsync();
-    for (int g0 = 0; g0 < a.nblocks; g0 += 64) {
-      const int gi = g0 + lane;
-      const bool valid = gi < a.nblocks;
-      const int cls = valid ? ord_cost[gi] : 0;
-      const unsigned long long m = same_class(cls, valid);
-      const int base = ord_pos[cls];
-      if (valid) a.grp_order[base + __popcll(m & lt)] = gi;  // within a class: ascending group index
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (met) {  // (never false in practice; the order of the previous refresh then simply stays)
+      if (lane < 16) {  // where this wave's slice starts inside class `lane`
+        int run = 0;
+        for (int c = 0; c < lane; ++c)
+          for (int w = 0; w < kSortWaves; ++w) run += ord_cnt[w][c];
+        for (int w = 0; w < sw; ++w) run += ord_cnt[w][lane];
+        ord_pos[sw][lane] = run;
+      }
       wsync();
-      if (valid && (m & lt) == 0) ord_pos[cls] = base + __popcll(m);
-      wsync();
+      for (int g0 = g_first; g0 < g_last; g0 += 64) {
+        const int gi = g0 + lane;
+        const bool valid = gi < g_last;
+        const int cls = valid ? ord_cls[gi] : 0;
+        const unsigned long long m = same_class(cls, valid);
+        const int base = ord_pos[sw][cls];
+        if (valid) a.grp_order[base + __popcll(m & lt)] = gi;  // within a class: ascending group index
+        wsync();
+        if (valid && (m & lt) == 0) ord_pos[sw][cls] = base + __popcll(m);
+        wsync();
+      }
+      if (sw == 0 && lane == 0) st->order_valid = 1;
     }
-    if (lane == 0) st->order_valid = 1;
-    if (a.dbg_stamps && lane == 0) a.dbg_stamps[7] = __builtin_amdgcn_s_memtime() - t_ord;
+    if (a.dbg_stamps && sw == 0 && lane == 0) a.dbg_stamps[7] = __builtin_amdgcn_s_memtime() - t_ord;
   }
   if (wave != 0) return;
   if (a.mode == 2) {  // compute_error hook
