@@ -50,8 +50,11 @@ def _compare_linearisation(g, o, T):
     assert np.array_equal(sg[cg >= 0], so[co >= 0])              # float32 squared distances, bit for bit
     differ = cg != co
     assert differ.mean() < 1e-3                                  # only exact-distance ties may pick another index (checked above: equal d2)
-    assert abs(eg - eo) <= 1e-9 * abs(eo)
-    assert np.abs(Hg - Ho).max() <= 1e-9 * np.abs(Ho).max() and np.abs(bg - bo).max() <= 1e-9 * np.abs(bo).max()
+    # a tie resolved the other way swaps one target point (and its covariance) for an equidistant one: each moves the sums by up to
+    # about one term in len(cg)
+    tol = 1e-9 + 10.0 * differ.sum() / len(cg)
+    assert abs(eg - eo) <= tol * abs(eo)
+    assert np.abs(Hg - Ho).max() <= tol * np.abs(Ho).max() and np.abs(bg - bo).max() <= tol * np.abs(bo).max(), (int(differ.sum()), np.abs(Hg - Ho).max() / np.abs(Ho).max())
     return int(differ.sum())
 
 
@@ -120,3 +123,15 @@ def test_c5_dense_os1_250k_2m(ng, oracle_mod, settings):
     assert len(w.source) == 250_000 and len(w.target) == 2_000_000
     r = _run_case(ng, oracle_mod, w, 20, w.max_corr_dist, settings, w.guess, w.keyframe_sizes)
     print("c5", r)
+
+
+def test_source_larger_than_the_sorted_launch_list(ng, oracle_mod):
+    """A 500k-point SOURCE (the submap aligned back onto the scan): more groups of query batches than the solver sorts into a launch
+    list (kMaxOrderGroups = 4096), so the pass runs in index order and the solver reduces its rows in several steps - the largest
+    grid any configuration launches.  Same checks as the BASELINE configurations."""
+    from types import SimpleNamespace
+    w = clouds.scan_to_submap(100_000, 5)
+    inv = np.linalg.inv(np.asarray(w.guess, np.float64)).astype(np.float32)
+    sw = SimpleNamespace(source=w.target, target=w.source)
+    r = _run_case(ng, oracle_mod, sw, 10, 1.0, DLO, inv)
+    print("500k source", r)
