@@ -172,6 +172,17 @@ def test_covariances_match_oracle(ng, oracle_mod, reg, k):
     assert np.abs(a - a.transpose(0, 2, 1)).max() == 0.0
 
 
+@pytest.mark.parametrize("k", [3, 7, 15, 25, 32])
+def test_covariances_k_off_the_list_sizes(ng, oracle_mod, k):
+    """k that is not one of the compiled list sizes (10 / 20 / 32): the list is longer than k, the k-th best sits in either lane of
+    the pair, and the neighbour sums stop inside a lane's half."""
+    w = clouds.scan_to_scan(10_000)
+    g = ng.NanoGICP(); g.setCorrespondenceRandomness(k); g.setInputSource(w.source); g.calculateSourceCovariances()
+    a, b = g.getSourceCovariances(), oracle_mod.covariances(w.source, k, 3)
+    ties = _boundary_ties(oracle_mod, w.source, k)
+    assert ties.mean() < 5e-3 and np.abs(a - b)[~ties].max() < 1e-9
+
+
 def test_set_get_covariances_roundtrip_and_reorder(ng):
     w = clouds.scan_to_scan(10_000)
     g = ng.NanoGICP(); g.setInputSource(w.source); g.setInputTarget(w.target)
