@@ -155,6 +155,7 @@ constexpr int kStageMaxGrow = 6;
 #ifndef NGICP_WALK_WINDOW
 #define NGICP_WALK_WINDOW 12
 #endif
+
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
 static_assert(kWalkWindow <= kSortedPad && kWalkWindow % 2 == 0, "walk windows may overhang the array by at most the sentinel frame");
 
@@ -189,7 +190,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // x-gap alone rules the rest out.  Any start is correct (a side only stops once it is past qx AND out of reach); a good
 // start (interpolated from the cell geometry: points of a dense scan line are nearly equidistant in x) makes the cost
 // O(points within reach) with no search at all.  This is what keeps dense scan lines affordable.
-template <int W = kWalkWindow>
+template <int W = kWalkWindow, int kStep = kWalkWindow>
 __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
                                                     float& best, int& pos, unsigned int& ncand, unsigned int& gsteps) {
   if (e <= s) return;
@@ -200,37 +201,46 @@ __device__ __forceinline__ void scan_global_outward(const float4* __restrict__ t
   // smallest / largest x and, among equal distances, the first one met has the smallest position (strict `<` below).
   // Most walks end after the first window: both neighbours are ruled out by their x-gap alone.
   int w = m - W / 2, dir = 0, lo = m - W / 2, hi = m - W / 2 + W;  // [lo, hi) has been read
+  int wn = W;  // points of the current window: W around the start, kStep on either side after that.  Measured with W = 12: side windows
+               // of 8 / 6 / 4 points examine 8 / 12 / 16 % fewer candidates and cost c3 +3 / +7 / +18 %, c2 +1 / +6 / +16 % in time (more
+               // dependent steps) but c5 -3 % (8 points): the build for large grids, bound by what its waves fetch, uses 8
+  static_assert(kStep >= 2 && kStep <= W, "side windows are at most as long as the first");
   bool go_left = false;
   for (;;) {
     // No index clamps: a window that overhangs [s, e) reads points of the neighbouring runs (genuine target points: they can
     // only be legitimate candidates) or the sentinels that frame the array (infinitely far).  The x-gap tests below only
-    // look at c[7] / c[0] when the window's right / left end is inside the run.
+    // look at the window's last / first point when its right / left end is inside the run.
     const float4* __restrict__ q = tgt + w;  // one address, immediate offsets
     float4 c[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) c[j] = q[j];
+    for (int j = 0; j < W; ++j)
+      if (j < kStep || wn == W) c[j] = q[j];
     float lb = sqdist(qx, qy, qz, c[0]);
     int lj = 0;
 #pragma unroll
     for (int j = 1; j < W; ++j) {
-      const float d = sqdist(qx, qy, qz, c[j]);
-      if (d < lb) { lb = d; lj = j; }
+      if (j < kStep || wn == W) {
+        const float d = sqdist(qx, qy, qz, c[j]);
+        if (d < lb) { lb = d; lj = j; }
+      }
     }
     if (nn_better(lb, w + lj, best, pos)) { best = lb; pos = w + lj; }
-    ncand += W;
+    ncand += wn;
     ++gsteps;
-    const float lim = fminf(best, gate_sq), dr = c[W - 1].x - qx, dl = qx - c[0].x;
+    const float lim = fminf(best, gate_sq), dr = (wn == W ? c[W - 1].x : c[kStep - 1].x) - qx, dl = qx - c[0].x;
     const bool more_right = hi < e && !(dr > 0.f && dr * dr + gyz > lim);
     const bool more_left = lo > s && !(dl > 0.f && dl * dl + gyz > lim);
     if (dir == 0) go_left = more_left;
     if (dir >= 0 && more_right) {
       dir = 1;
       w = hi;
-      hi += W;
+      hi += kStep;
+      wn = kStep;
     } else if (dir >= 0 ? go_left : more_left) {
       dir = -1;
-      lo -= W;
+      lo -= kStep;
       w = lo;
+      wn = kStep;
     } else {
       break;
     }
@@ -306,6 +316,7 @@ constexpr int kStampStride = 24;
 template <int G, int WPS = NGICP_PASS_WAVES>
 __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   constexpr int B = 64 / G;  // queries per wave batch
+  constexpr int kSideStep = WPS >= 4 ? (kWalkWindow * 2) / 3 : kWalkWindow;  // (see scan_global_outward)
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
   __shared__ WaveStage stage_all[4];
@@ -561,7 +572,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           int up = (int)(unsigned int)k0;
           if (gyz > fminf(ub, a.gate_sq_f)) continue;
           const unsigned int c_before = ncand;
-          scan_global_outward(a.tgt, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          scan_global_outward<kWalkWindow, kSideStep>(a.tgt, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
           atomicMin(&S.qkey[qs], pack_key(ub, up));
           if (a.dbg_qstats) {
             atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
@@ -633,7 +644,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
               const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
               const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
               const unsigned int c_before = ncand;
-              scan_global_outward(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              scan_global_outward<kWalkWindow, kSideStep>(a.tgt, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
               atomicMin(&S.qkey[qs], pack_key(ub, up));
               if (a.dbg_qstats) {
                 atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
