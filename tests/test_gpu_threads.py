@@ -1,0 +1,70 @@
+"""GPU tests (-m gpu): several handles driven from several host threads at once.  DLO's node runs under ros::AsyncSpinner(0)
+(src/dlo/odom_node.cc): a handle has one caller at a time, but different handles are called from different threads, and the
+engine's process-wide pools (index objects, covariance buffers) and the event fences between the handles' streams are shared by
+all of them.  Results must be those of the same calls made one after the other, bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+
+from direct_lidar_odometry_amd import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ng(hip_lib):
+    from direct_lidar_odometry_amd import nano_gicp
+    return nano_gicp
+
+
+def _frames(ng, w, scans):
+    """The per-frame sequence of odom.cc:498-526, 803-840 on a private pair of handles; returns every pose and the last covariances."""
+    s2s, s2m = ng.NanoGICP(), ng.NanoGICP()
+    for e, k, d in ((s2s, 10, 1.0), (s2m, 20, 0.5)):
+        e.setCorrespondenceRandomness(k); e.setMaxCorrespondenceDistance(d); e.setMaximumIterations(32); e.setTransformationEpsilon(0.01)
+    s2m.setInputTarget(w.target); s2m.calculateTargetCovariances()
+    out = []
+    prev = None
+    for scan in scans:
+        s2s.setInputSource(scan); s2s.calculateSourceCovariances()
+        if prev is not None:
+            s2s.align()
+            out.append(s2s.getFinalTransformation().copy())
+        s2m.registerInputSource(scan); s2m.shareSourceIndexFrom(s2s); s2m.copySourceCovariancesFrom(s2s)
+        s2m.align(w.guess)
+        out.append(s2m.getFinalTransformation().copy())
+        s2s.swapSourceAndTarget()   # odom.cc:818: the scan becomes the next frame's target
+        prev = scan
+    covs = s2m.getSourceCovariances().copy()
+    s2s.close(); s2m.close()
+    return out, covs
+
+
+def test_handles_on_concurrent_threads_give_the_serial_results(ng):
+    w = clouds.scan_to_submap(20_000, 3)
+    n_threads, n_frames = 4, 5
+    scans = [[np.ascontiguousarray(w.source + np.float32(1e-3 * (5 * t + i))) for i in range(n_frames)] for t in range(n_threads)]
+    serial = [_frames(ng, w, scans[t]) for t in range(n_threads)]
+    results, errors = [None] * n_threads, []
+
+    def work(t):
+        try:
+            results[t] = _frames(ng, w, scans[t])
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((t, repr(e)))
+
+    for _ in range(2):  # twice: the second round runs on recycled pool objects
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=120)
+        assert not errors, errors
+        assert all(not th.is_alive() for th in threads)
+        for t in range(n_threads):
+            poses, covs = results[t]
+            assert len(poses) == len(serial[t][0])
+            for a, b in zip(poses, serial[t][0]):
+                assert np.array_equal(a, b)
+            assert np.array_equal(covs, serial[t][1])
