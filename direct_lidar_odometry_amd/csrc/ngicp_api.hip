@@ -87,6 +87,8 @@ struct DeviceCloud {
   DevBuf sorted;      // float4[kSortedPad + n + kSortedPad]: the cell-sorted points between two runs of far-away sentinels, so
                       // that the 8-point windows of the search may overhang the array's ends without index clamps
   float4* pts() const { return sorted.as<float4>() + kSortedPad; }
+  DevBuf sorted3;     // Xyz[kSortedPad + n + kSortedPad]: the same points and sentinels, 12 bytes each (the pass kernel's walks)
+  Xyz* xyz3() const { return sorted3.as<Xyz>() + kSortedPad; }
   DevBuf perm;        // int[n]    sorted position -> original index
   DevBuf inv_perm;    // int[n]    original index -> sorted position (lazily built)
   bool has_inv = false;
@@ -469,6 +471,8 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
                      h->fill.as<int>(), h->tmp.as<float4>());
   hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cells(), dc->pts(),
                      dc->perm.as<int>());
+  dc->sorted3.ensure((n + 2 * kSortedPad) * sizeof(Xyz));
+  hipLaunchKernelGGL(k_pack_xyz, dim3((unsigned)((n + 2 * kSortedPad + 255) / 256)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni + 2 * kSortedPad, dc->sorted3.as<Xyz>());
   {
     // query order (Morton over tiles of 2^shift cells; <= 128 tiles per axis => <= 2M histogram bins)
     int shift = 2;
@@ -684,6 +688,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
   a.n_src = (int)n;
   a.tgt = T.pts();
+  a.tgt3 = T.xyz3();
   a.tgt_cell_start = T.cells();
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
