@@ -335,7 +335,11 @@ constexpr int kStampStride = 24;
 template <int G, int WPS = NGICP_PASS_WAVES>
 __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   constexpr int B = 64 / G;  // queries per wave batch
-  constexpr int kSideStep = WPS >= 4 ? (kWalkWindow * 2) / 3 : kWalkWindow;  // (see scan_global_outward)
+  // Walk windows (see scan_global_outward), measured with the packed points: the default build, whose launches are as long as their
+  // slowest chain of window steps, does best with 16-point windows (c3 35.4 -> 34.3 us, c2 32.0 -> 31.2 us against 12; 18 and more
+  // cost registers and time); the build for large grids, bound by what its waves fetch, with 12 points and 8-point side windows.
+  constexpr int kWin = WPS >= 4 ? 12 : 16, kSideStep = WPS >= 4 ? 8 : 16;
+  static_assert(kWin <= kSortedPad, "walk windows may overhang the array by at most the sentinel frame");
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
   __shared__ WaveStage stage_all[4];
@@ -591,7 +595,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           int up = (int)(unsigned int)k0;
           if (gyz > fminf(ub, a.gate_sq_f)) continue;
           const unsigned int c_before = ncand;
-          scan_global_outward<kWalkWindow, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          scan_global_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
           atomicMin(&S.qkey[qs], pack_key(ub, up));
           if (a.dbg_qstats) {
             atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
@@ -663,7 +667,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
               const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
               const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
               const unsigned int c_before = ncand;
-              scan_global_outward<kWalkWindow, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              scan_global_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
               atomicMin(&S.qkey[qs], pack_key(ub, up));
               if (a.dbg_qstats) {
                 atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
