@@ -1,15 +1,16 @@
 """Diagnostic: when and on which CU every block of the LAST pass of an align ran (NGICP_DEBUG_SPAN).
-usage: python scripts/spans.py [c3|c2|c5]"""
+usage: python scripts/spans.py [c3|c2|c5] [iterations]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from direct_lidar_odometry_amd import clouds
 from direct_lidar_odometry_amd.nano_gicp import NanoGICP, keyframe_covariances
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20  # the timeline is that of the LAST pass: fewer iterations look inside an alignment
 w = clouds.scan_to_submap(100_000, 5) if cfg == "c3" else (clouds.scan_to_scan(100_000) if cfg == "c2" else clouds.scan_to_submap(250_000, 8, shape="os1"))
 g = NanoGICP()
 g.setMaxCorrespondenceDistance(w.max_corr_dist)
-g.setMaximumIterations(20); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
+g.setMaximumIterations(iters); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
 g.setInputTarget(w.target); g.setInputSource(w.source)
 if cfg == "c2":
     g.calculateTargetCovariances()
