@@ -484,30 +484,25 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
     h->fill.ensure((size_t)(nbins + 1 + kCellPad) * sizeof(int));  // reused as tile_start (k_scan_apply pads its output)
     HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(nbins + 1) * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_tile_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, h->counts.as<int>());
+    // where every tile's queries start and where its batches start: one scan of packed {count, ceil(count / 32)} pairs
     const int ntiles = (nbins + kScanTile - 1) / kScanTile;
-    h->tile_sums.ensure((size_t)ntiles * sizeof(int));
-    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)nullptr,
-                       (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<int>(), h->fill.as<int>());
+    h->tile_sums.ensure((size_t)ntiles * sizeof(unsigned long long));
+    h->tmp.ensure(std::max(n * sizeof(float4), (size_t)(nbins + 1 + kCellPad) * sizeof(int)));  // (k_cell_rank is done with it) batches before every tile
+    dc->n_batches_dev.ensure(sizeof(int));
+    hipLaunchKernelGGL(k_scan2_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<unsigned long long>());
+    hipLaunchKernelGGL(k_scan2_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<unsigned long long>(), ntiles);
+    hipLaunchKernelGGL(k_scan2_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->counts.as<int>(), nbins, h->tile_sums.as<unsigned long long>(), h->fill.as<int>(),
+                       h->tmp.as<int>(), dc->n_batches_dev.as<int>());
     dc->qpts.ensure(n * sizeof(float4));
     hipLaunchKernelGGL(k_tile_place, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, dc->pts(), ni, g, shift, dc->cells(),
                        h->fill.as<int>(), dc->qpts.as<float4>());
     // tile-aligned query batches
-    h->keys.ensure((size_t)(nbins + 1) * sizeof(int));   // batches per tile
-    h->tmp.ensure((size_t)(nbins + 1 + kCellPad) * sizeof(int));    // exclusive scan of it
     dc->batches.ensure((n + 1) * sizeof(int2));
-    dc->n_batches_dev.ensure(sizeof(int));
-    hipLaunchKernelGGL(k_batch_count, dim3((nbins + 255) / 256), dim3(256), 0, h->stream, h->counts.as<int>(), nbins, h->keys.as<int>());
-    hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->keys.as<int>(), nbins, h->tile_sums.as<int>(), (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kScanBlock), 0, h->stream, h->tile_sums.as<int>(), ntiles, (const unsigned long long*)nullptr,
-                       (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_scan_apply, dim3(ntiles), dim3(kScanBlock), 0, h->stream, h->keys.as<int>(), nbins, h->tile_sums.as<int>(), h->tmp.as<int>());
     hipLaunchKernelGGL(k_batch_fill, dim3((nbins + 255) / 256), dim3(256), 0, h->stream, h->counts.as<int>(), h->fill.as<int>(), h->tmp.as<int>(), nbins,
-                       dc->batches.as<int2>(), dc->n_batches_dev.as<int>());
+                       dc->batches.as<int2>());
     dc->batch_boxes.ensure((n + 1) * 6 * sizeof(float));
-    hipLaunchKernelGGL(k_batch_boxes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dc->qpts.as<float4>(), dc->batches.as<int2>(), dc->n_batches_dev.as<int>(),
-                       dc->batch_boxes.as<float>());
+    hipLaunchKernelGGL(k_batch_boxes, dim3((unsigned)std::min<size_t>((n + 3) / 4, 4096)), dim3(256), 0, h->stream, dc->qpts.as<float4>(), dc->batches.as<int2>(), dc->n_batches_dev.as<int>(),
+                       dc->batch_boxes.as<float>());  // (a wave per batch, grid-strided)
     HIP_TRY(hipMemcpyAsync(&dc->n_batches, dc->n_batches_dev.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   }
   // with a memoised voxel the occupancy read-back rides on the build's final synchronisation (it steers the memo for the

@@ -239,6 +239,92 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int* __restrict
   }
 }
 
+// The tile pipeline needs two exclusive scans over the same histogram: of the tile counts (where a tile's queries start) and of the
+// tiles' batch counts, ceil(count / 32) (where its batches start).  Both ride in ONE scan of packed 64-bit values (count in the low
+// word, batches in the high word: neither sum reaches 2^31), three launches instead of seven.
+__device__ __forceinline__ unsigned long long pack_tile(int count) {
+  return (unsigned long long)(unsigned int)count | ((unsigned long long)(unsigned int)((count + 31) >> 5) << 32);
+}
+__device__ __forceinline__ unsigned long long block_exclusive_scan64(unsigned long long v, unsigned long long* lds /*>= 4*/, unsigned long long& block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  unsigned long long wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    const unsigned long long s = lds[w];
+    if (w < wave) wave_off += s;
+    total += s;
+  }
+  __syncthreads();
+  block_total = total;
+  return wave_off + inc - v;
+}
+__global__ void __launch_bounds__(kScanBlock) k_scan2_tiles(const int* __restrict__ counts, int n, unsigned long long* __restrict__ tile_sums) {
+  __shared__ unsigned long long lds[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  unsigned long long s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) s += (base + j < n) ? pack_tile(counts[base + j]) : 0ull;
+  unsigned long long total;
+  block_exclusive_scan64(s, lds, total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(kScanBlock) k_scan2_tile_sums(unsigned long long* __restrict__ tile_sums, int ntiles) {  // single block, in place
+  __shared__ unsigned long long lds[4];
+  __shared__ unsigned long long carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += kScanBlock) {
+    const int i = base + threadIdx.x;
+    const unsigned long long v = (i < ntiles) ? tile_sums[i] : 0ull;
+    unsigned long long total;
+    const unsigned long long ex = block_exclusive_scan64(v, lds, total);
+    const unsigned long long carry = carry_s;
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+}
+// start[i] / bstart[i] = exclusive prefixes of count / ceil(count / 32); start has n + 1 + kCellPad entries (as k_scan_apply writes
+// them), *n_batches = the total number of batches
+__global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const int* __restrict__ counts, int n, const unsigned long long* __restrict__ tile_offsets, int* __restrict__ start,
+                                                            int* __restrict__ bstart, int* __restrict__ n_batches) {
+  __shared__ unsigned long long lds[4];
+  const int base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  unsigned long long c[kScanPerThread];
+  unsigned long long s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    c[j] = (base + j < n) ? pack_tile(counts[base + j]) : 0ull;
+    s += c[j];
+  }
+  unsigned long long total;
+  unsigned long long ex = block_exclusive_scan64(s, lds, total) + tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanPerThread; ++j) {
+    const int i = base + j;
+    if (i < n) {
+      start[i] = (int)(unsigned int)ex;
+      bstart[i] = (int)(ex >> 32);
+    }
+    ex += c[j];
+    if (i == n - 1) {
+#pragma unroll
+      for (int t = 0; t <= kCellPad; ++t) start[n + t] = (int)(unsigned int)ex;
+      bstart[n] = (int)(ex >> 32);
+      *n_batches = (int)(ex >> 32);
+    }
+  }
+}
+
 // scatter into cell segments (arbitrary order inside a cell)
 __global__ void __launch_bounds__(256) k_cell_scatter(const float4* __restrict__ pts, const int* __restrict__ keys, int n, const int* __restrict__ cell_start,
                                                        int* __restrict__ fill, float4* __restrict__ tmp) {
@@ -350,39 +436,45 @@ __global__ void k_fill_sentinels(float4* __restrict__ padded, int n) {
 // boundary, so a batch's bounding box is at most one tile.  batch[b] = {first qpts index, count}.
 constexpr int kBatchQueries = 32;
 
-__global__ void __launch_bounds__(256) k_batch_count(const int* __restrict__ tile_counts, int nbins, int* __restrict__ nb) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < nbins) nb[t] = (tile_counts[t] + kBatchQueries - 1) / kBatchQueries;
-}
 __global__ void __launch_bounds__(256) k_batch_fill(const int* __restrict__ tile_counts, const int* __restrict__ tile_start, const int* __restrict__ batch_start,
-                                                     int nbins, int2* __restrict__ batches, int* __restrict__ n_batches) {
+                                                     int nbins, int2* __restrict__ batches) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nbins) return;
   const int cnt = tile_counts[t];
   const int b0 = batch_start[t], q0 = tile_start[t];
   for (int j = 0, done = 0; done < cnt; ++j, done += kBatchQueries) batches[b0 + j] = make_int2(q0 + done, min(kBatchQueries, cnt - done));
-  if (t == nbins - 1) *n_batches = b0 + (cnt + kBatchQueries - 1) / kBatchQueries;
 }
 
 // Axis-aligned bounding box (metric, cloud frame) of every query batch: {cx, cy, cz, hx, hy, hz} centre and
 // half extents.  The pass kernel transforms it with the trial pose instead of reducing over lanes.
 __global__ void __launch_bounds__(256) k_batch_boxes(const float4* __restrict__ qpts, const int2* __restrict__ batches, const int* __restrict__ n_batches,
                                                       float* __restrict__ boxes6) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= *n_batches) return;
+  // a wave per batch, a lane per query (a thread per batch walked its 32 queries one dependent load after the other)
+  const int lane = threadIdx.x & 63, nb = *n_batches;
+  for (int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nb; b += (gridDim.x * blockDim.x) >> 6) {
   const int2 bd = batches[b];
   float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int j = 0; j < bd.y; ++j) {
+  for (int j = lane; j < bd.y; j += 64) {
     const float4 p = qpts[bd.x + j];
     mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
     mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
     mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
   }
-  float* o = boxes6 + (size_t)b * 6;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    o[d] = 0.5f * (mn[d] + mx[d]);
-    o[3 + d] = 0.5f * (mx[d] - mn[d]);
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[d] = fminf(mn[d], __shfl_xor(mn[d], o));
+      mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], o));
+    }
+  if (lane == 0) {
+    float* o = boxes6 + (size_t)b * 6;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      o[d] = 0.5f * (mn[d] + mx[d]);
+      o[3 + d] = 0.5f * (mx[d] - mn[d]);
+    }
+  }
   }
 }
 
