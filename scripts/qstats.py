@@ -10,6 +10,8 @@ w = clouds.scan_to_submap(100_000, 5) if cfg == "c3" else (clouds.scan_to_scan(1
 g = NanoGICP()
 g.setMaxCorrespondenceDistance(w.max_corr_dist)
 g.setMaximumIterations(20); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
+if os.environ.get("QSTATS_COLD"):  # the FIRST pass of an alignment (no previous correspondences): one Gauss-Newton iteration
+    g.setOptimizer(0); g.setMaximumIterations(1)
 g.setInputTarget(w.target); g.setInputSource(w.source)
 if cfg == "c2":
     g.calculateTargetCovariances()
