@@ -349,7 +349,7 @@ def main():
 
     for _ in range(args.warmup):
         g.align(w.guess)
-    g.setProfiling(7)  # HIP events around every 7th pass launch: 3 of the 21 per align (an event between two kernels costs stream time)
+    g.setProfiling(7)  # events attached to every 7th pass launch (3 of the 21 per align): the kernel's own begin / end timestamps
     iters_done = 0
     passes = 0
     pass_ms = 0.0

@@ -4,6 +4,7 @@
 #include "../../include/ngicp.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -633,16 +634,18 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
 // ------------------------------------------------------------------------------------------
 // Registration loop
 // ------------------------------------------------------------------------------------------
-void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s) {
-  // 32-query batches, 2 lanes per query.  Two builds of the kernel: 3 waves per SIMD (134 VGPRs), and 4 (128 VGPRs, a few spilled
+// start / stop: events attached to the dispatch itself (they take the kernel's own begin / end timestamps: no extra packets in
+// the stream, unlike hipEventRecord before and after), or null
+void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+  // 32-query batches, 2 lanes per query.  Two builds of the kernel: 3 waves per SIMD (129 VGPRs), and 4 (128 VGPRs, two spilled
   // dwords, 4 blocks per CU) for grids of more than two rounds of blocks, where the launch is bound by how many blocks pass through
   // the chip rather than by its slowest block.
   static const int force = std::getenv("NGICP_PASS_WPS") ? std::atoi(std::getenv("NGICP_PASS_WPS")) : 0;  // (A/B timing only)
   const bool four = force ? force == 4 : nblocks > 2 * h->pass_slots;
   if (four)
-    hipLaunchKernelGGL((k_gicp_pass<2, 4>), dim3(nblocks), dim3(256), 0, s, a);
+    hipExtLaunchKernelGGL((k_gicp_pass<2, 4>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, a);
   else
-    hipLaunchKernelGGL((k_gicp_pass<2, 3>), dim3(nblocks), dim3(256), 0, s, a);
+    hipExtLaunchKernelGGL((k_gicp_pass<2, 3>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, a);
 }
 
 struct LoopCtx {
@@ -872,9 +875,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       continue;
     }
     const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
-    if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched], h->stream));
-    launch_pass(h, c.pa, c.nblocks, h->stream);
-    if (timed) HIP_TRY(hipEventRecord(h->prof_events[2 * launched + 1], h->stream));
+    launch_pass(h, c.pa, c.nblocks, h->stream, timed ? h->prof_events[2 * launched] : nullptr, timed ? h->prof_events[2 * launched + 1] : nullptr);
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     ++launched;
   }
