@@ -269,6 +269,7 @@ struct ngicp {
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
   int pass_slots = 768;  // blocks of the 3-waves-per-SIMD pass kernel resident on this device at once
+  double prev_staged_fraction = -1.0;  // share of the queries the previous alignment served through row lists (-1: none yet)
   DevBuf dbg, dbg_q, dbg_s, dbg_span, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
@@ -825,6 +826,11 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   st.order_valid = (h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks) ? 1 : 0;
   h->order_src = nullptr;  // set again below, once this align has left a complete order behind
   c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
+  // Whether the FIRST pass lists the region rows of every batch (later passes list for the batches that looked beyond ring 1 in the
+  // pass before): it pays where many queries do (100k -> 500k with DLO's settings: 22 % of the batches, scan-to-submap 0.67 -> 0.64 ms)
+  // and costs where few do (250k -> 2M: first pass 107 -> 72 us without).  Decided from the share of queries the previous alignment
+  // of this handle served through lists; yes when there was none.
+  if (h->prev_staged_fraction < 0.0 || h->prev_staged_fraction >= 0.12) c.pa.mode |= 32;
   if (const char* dbg = std::getenv("NGICP_DEBUG_MODE")) c.pa.mode |= (std::atoi(dbg) & (8 | 16));  // timing experiments only
   if (h->p.max_iter <= 0) st.hot.done = 1;
   h->pin_state[0] = st;
@@ -952,6 +958,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   s.mean_candidates = st.hot.passes > 0 ? st.hot.cand_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
   s.valid_fraction = st.hot.passes > 0 ? st.hot.valid_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
   s.staged_fraction = st.hot.passes > 0 ? st.hot.staged_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
+  if (st.hot.passes > 1) h->prev_staged_fraction = s.staged_fraction;
   s.pass_ms_total = 0.0;
   if (h->profiling) {
     // HIP events on the handle's own stream around every pass launch that did work
@@ -1444,6 +1451,7 @@ int ngicp_sharded_begin(ngicp_t* h, const float guess[16]) {
     LoopCtx& c = *h->shard_ctx;
     prepare_loop(h, c);
     c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
+    if (h->prev_staged_fraction < 0.0 || h->prev_staged_fraction >= 0.12) c.pa.mode |= 32;  // (see do_align)
     LmState st;
     init_state_from_pose(st, pose_from_colmajor_f(guess ? guess : I));
     if (h->p.max_iter <= 0) st.hot.done = 1;

@@ -112,7 +112,7 @@ struct PassArgs {
                             // are the outer rings of the batch region listed (a wrong guess costs time, not exactness)
   LmState* st;
   double* partials;         // [n_groups][kNumSlots], group-major: a block stores its 32 sums as one 256-byte row
-  int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks)
+  int mode;                 // bit0: error part, bit1: linearise part, bit2: ignore st->done (test hooks), bit5: the first pass lists region rows
   int stage_grow;           // rings around the batch box that the LDS row list covers (0: no list, search unindexed)
   unsigned long long* dbg_stamps;  // diagnostic only: [wave][kStampStride] s_memtime stamps + counters, or null
   int4* dbg_qstats;                // diagnostic only: per query {ring-1 candidates, ring-1 walks | far walks << 16, far + shell candidates, flags}, or null
@@ -459,9 +459,8 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
       int Y0 = 0, Z0 = 0, wy = 1, grow = 0, nlive = 0;
       int b0x = 0, b0y = 0, b0z = 0, b1x = 0, b1y = 0, b1z = 0;
       bool listed = false;
-      // (The first pass of an alignment lists nothing: it has no flags yet, and listing for every batch cost it more than the
-      // unlisted search of the queries that do look beyond ring 1 - 107 -> 72 us at c5, and 2-4 % of every alignment.)
-      if (a.stage_grow >= 2 && have_prev && a.batch_far[batch] != 0) {  // wave-uniform
+      // (The first pass of an alignment has no flags yet: it lists for every batch or for none, as the host decides - mode bit 5.)
+      if (a.stage_grow >= 2 && (have_prev ? a.batch_far[batch] != 0 : (a.mode & 32) != 0)) {  // wave-uniform
         {
           const float* bb = a.batch_boxes + (size_t)batch * 6;
           const float bcx = bb[0], bcy = bb[1], bcz = bb[2], bhx = bb[3], bhy = bb[4], bhz = bb[5];
