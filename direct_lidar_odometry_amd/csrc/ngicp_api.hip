@@ -340,7 +340,8 @@ Grid make_grid(const float mn[3], const float mx[3], double h, int max_cells) {
   for (int d = 0; d < 3; ++d) ext[d] = std::max(0.0, (double)mx[d] - (double)mn[d]);
   for (;;) {
     double nx = std::floor(ext[0] / h) + 1, ny = std::floor(ext[1] / h) + 1, nz = std::floor(ext[2] / h) + 1;
-    if (nx * ny * nz <= (double)max_cells) {
+    // (the pass kernel packs a listed row as y | z << 16 in one int: y < 65536, z < 32768)
+    if (nx * ny * nz <= (double)max_cells && ny < 65536.0 && nz < 32768.0) {
       g.nx = (int)nx;
       g.ny = (int)ny;
       g.nz = (int)nz;
@@ -1851,6 +1852,10 @@ int ngicp_map_voxel_filter(ngicp_t* h, float leaf, size_t* n_out) {
     char err[256] = {0};
     const float4* out = nullptr;
     int m = 0;
+    // The filter workspace is shared with ngicp_preprocess_scan: whatever that call left there (h->filt_out points into it) is
+    // overwritten or reallocated now, so a later ngicp_set_source_preprocessed must find nothing rather than stale memory.
+    h->filt_out = nullptr;
+    h->filt_n = 0;
     // voxelgrid.setInputCloud(dlo_map); voxelgrid.filter(*dlo_map)  (map.cc:102-104): the map is replaced by its centroids
     if (ngk_filter_cloud(h->stream, &h->fws, h->map_pts.as<float4>(), (int)h->map_n, 0, 0.f, leaf, &out, &m, err, sizeof(err))) throw ArgError{NGICP_ERR_HIP, err};
     if (out != h->map_pts.as<float4>()) {

@@ -315,7 +315,18 @@ class NanoGICP:
         self.nr_iterations_ = nit.value
         self.final_hessian_ = H.reshape(6, 6).T.copy()
         self._ck(rc)
+        if getattr(self, "_debug", False):
+            self._print_lm_table()
         return aligned
+
+    def _print_lm_table(self):
+        """setDebugPrint(true): the reference's banner and per-trial table (impl/lsq_registration_impl.hpp:95-99,183-189), printed
+        from the engine's trace after the device-resident loop has returned."""
+        print("********************************************\n***************** optimize *****************\n********************************************")
+        for it, trial, y0, yi, rho, lam, dn, _acc in self.lm_trace():
+            if int(trial) == 0:
+                print("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s" % ("i", "y0", "yi", "rho", "lambda", "|delta|", "dec"))
+            print("%5d %15g %15g %15g %15g %15g %5c" % (int(trial), y0, yi, rho, lam, dn, "x" if rho > 0.0 else " "))
 
     def getFinalTransformation(self): return self.final_transformation_
     def hasConverged(self) -> bool: return self.converged_

@@ -78,17 +78,30 @@ def sharded_align(engine, guess, dist, torch_device, max_passes: int = MAX_SHARD
     per-thread partial sum, impl/nano_gicp_impl.hpp:260-267), every rank advances the identical LM state machine.
     The engine reports `done` with a constant lag, identically on every rank, so all ranks leave the loop in the
     same step.  Returns the final 4x4 (identical on every rank)."""
+    import contextlib
     import torch
     dev = torch.device(torch_device)
-    sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=dev)
-    # the engine's kernels go onto torch's current stream, the stream the collective is ordered on
-    stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-    engine.sharded_begin(guess)
-    for _ in range(max_passes):
-        engine.sharded_pass(sums.data_ptr(), stream)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        if engine.sharded_step(sums.data_ptr(), stream):
-            break
+    # The engine's kernels and the collective must be ordered on ONE stream.  The C ABI reads a null stream handle as "the engine's
+    # own stream" (hipStreamNonBlocking: not ordered against the legacy null stream), and torch's default stream IS the null handle,
+    # so the loop runs on a stream of its own, made current for the collective and handed to the engine by its (non-zero) handle.
+    if dev.type == "cuda":
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        ctx, stream = torch.cuda.stream(side), side.cuda_stream
+        assert stream != 0
     else:
-        raise RuntimeError("sharded_align: the alignment did not report completion")  # (bounded: a hang would take the node)
-    return engine.sharded_finish()
+        side, ctx, stream = None, contextlib.nullcontext(), 0
+    with ctx:
+        sums = torch.zeros(SUMS_LEN, dtype=torch.float64, device=dev)
+        engine.sharded_begin(guess)
+        for _ in range(max_passes):
+            engine.sharded_pass(sums.data_ptr(), stream)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            if engine.sharded_step(sums.data_ptr(), stream):
+                break
+        else:
+            raise RuntimeError("sharded_align: the alignment did not report completion")  # (bounded: a hang would take the node)
+        T = engine.sharded_finish()  # synchronises the stepping stream
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+    return T

@@ -227,6 +227,7 @@ class NanoGICP {
       std::fprintf(stderr, "[NanoGICP] align(): %s\n", ngicp_last_error(h_));
       return;
     }
+    if (lm_debug_print_) print_lm_table();
     for (size_t i = 0; i < output.size(); ++i) {  // transformed xyz; the other fields stay as in the input
       output.points[i].data[0] = xyz_out[i * 3 + 0];
       output.points[i].data[1] = xyz_out[i * 3 + 1];
@@ -244,6 +245,24 @@ class NanoGICP {
     converged_ = conv != 0;
     nr_iterations_ = nit;
     if (rc != NGICP_OK) std::fprintf(stderr, "[NanoGICP] align(): %s\n", ngicp_last_error(h_));
+    else if (lm_debug_print_) print_lm_table();
+  }
+  // setDebugPrint(true): the reference prints a banner per align() and one row per LM trial while it optimises
+  // (impl/lsq_registration_impl.hpp:95-99,183-189: boost::format "%5d %15g %15g %15g %15g %15g %5c" of i, y0, yi, rho, lambda,
+  // |delta|, 'x' when rho > 0, a header in front of trial 0).  The loop runs on the device here, so the same table is printed
+  // from the engine's trace once align() has returned.
+  void print_lm_table() const {
+    size_t n = 0;
+    if (ngicp_get_lm_trace(h_, nullptr, 0, &n) != NGICP_OK) return;
+    std::vector<double> rows(n * 8);
+    if (n && ngicp_get_lm_trace(h_, rows.data(), n, &n) != NGICP_OK) return;
+    std::printf("********************************************\n***************** optimize *****************\n********************************************\n");
+    for (size_t r = 0; r < n; ++r) {
+      const double* q = &rows[r * 8];  // {outer iteration, trial, y0, yi, rho, lambda, |delta|, accepted}
+      if ((int)q[1] == 0) std::printf("--- LM optimization ---\n%5s %15s %15s %15s %15s %15s %5s\n", "i", "y0", "yi", "rho", "lambda", "|delta|", "dec");
+      std::printf("%5d %15g %15g %15g %15g %15g %5c\n", (int)q[1], q[2], q[3], q[4], q[5], q[6], q[4] > 0.0 ? 'x' : ' ');
+    }
+    std::fflush(stdout);
   }
   Matrix4 getFinalTransformation() const { return final_transformation_; }
   bool hasConverged() const { return converged_; }

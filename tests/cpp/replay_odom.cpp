@@ -194,7 +194,9 @@ static pcl::PointCloud<PointType>::Ptr load(const char* path) {
 int main(int argc, char** argv) {
   int a = 1;
   bool device_keyframes = false;
+  bool debug_print = false;
   if (a < argc && !std::strcmp(argv[a], "--device-keyframes")) device_keyframes = true, ++a;
+  if (a < argc && !std::strcmp(argv[a], "--debug-print")) debug_print = true, ++a;  // setDebugPrint(true) on the scan-to-submap instance
   if (argc - a < 3) return 2;
   const int n = std::atoi(argv[a++]);
   std::vector<pcl::PointCloud<PointType>::Ptr> scans;
@@ -203,6 +205,7 @@ int main(int argc, char** argv) {
   dlo::OdomNode node;
   if (!node.gicp_s2s.valid() || !node.gicp.valid()) return 3;
   node.device_keyframes = device_keyframes;
+  if (debug_print) node.gicp.setDebugPrint(true);
   node.current_scan = scans[0];
   node.initializeInputTarget();
   if (!device_keyframes) {

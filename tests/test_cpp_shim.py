@@ -104,6 +104,18 @@ def test_cpp_shim_replays_dlo_sequence_like_the_oracle(hip_lib, oracle_mod, tmp_
     res_dev = subprocess.run([exe, "--device-keyframes", str(len(scans)), *paths], capture_output=True, text=True, timeout=300)
     assert res_dev.returncode == 0, res_dev.stderr
     assert res_dev.stdout == res.stdout  # same clouds, same index build, same covariances: bit-identical poses
+    # setDebugPrint(true) (impl/lsq_registration_impl.hpp:79-81,95-99,183-189): the reference's banner and LM table on stdout, one
+    # banner per align() of that instance, a header in front of every trial 0, rows "%5d %15g x5 %5c"; nothing else changes
+    res_dbg = subprocess.run([exe, "--debug-print", str(len(scans)), *paths], capture_output=True, text=True, timeout=300)
+    assert res_dbg.returncode == 0, res_dbg.stderr
+    dbg_lines = res_dbg.stdout.splitlines()
+    assert dbg_lines.count("***************** optimize *****************") == len(scans) - 1
+    header = "%5s %15s %15s %15s %15s %15s %5s" % ("i", "y0", "yi", "rho", "lambda", "|delta|", "dec")
+    assert dbg_lines.count("--- LM optimization ---") == dbg_lines.count(header) >= len(scans) - 1
+    rows = [l for l in dbg_lines if len(l) == 5 + 5 * 16 + 6 and l[:5].strip().isdigit()]
+    assert len(rows) >= dbg_lines.count(header) and all(r.rstrip().endswith("x") or r.endswith(" ") for r in rows)
+    plain = [l for l in dbg_lines if l.split() and l.split()[0] in ("s2s", "s2m", "aligned", "covs")]
+    assert plain == res.stdout.splitlines()
     got = {"s2s": [], "s2m": [], "aligned": [], "covs": []}
     for line in res.stdout.splitlines():
         tag, *vals = line.split()

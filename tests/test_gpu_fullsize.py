@@ -42,20 +42,41 @@ def _check_covs(orc, pts, sizes, k, gpu_covs):
         lo += n
 
 
-def _compare_linearisation(g, o, T):
+def _point_terms(src, tgt, cs, ct, rows, corr, T):
+    """Sum over `rows` of the per-point terms of H, b and the error (impl/nano_gicp_impl.hpp:205-209,232-257) in float64 numpy."""
+    H, b, err = np.zeros((6, 6)), np.zeros(6), 0.0
+    R, t = T[:3, :3], T[:3, 3]
+    for i, j in zip(rows, corr):
+        M = np.linalg.inv(ct[j][:3, :3] + R @ cs[i][:3, :3] @ R.T)
+        ta = R @ src[i].astype(np.float64) + t
+        e = tgt[j].astype(np.float64) - ta
+        J = np.hstack([np.array([[0, -ta[2], ta[1]], [ta[2], 0, -ta[0]], [-ta[1], ta[0], 0.0]]), -np.eye(3)])
+        H += J.T @ M @ J
+        b += J.T @ M @ e
+        err += e @ M @ e
+    return H, b, err
+
+
+def _compare_linearisation(g, o, T, src, tgt, cs, ct):
     Hg, bg, eg = g.linearize(T)
     Ho, bo, eo = o.linearize(T)
     cg, sg = g.correspondences(); co, so = o.correspondences()
     assert np.array_equal(cg >= 0, co >= 0)                      # the same points pass the distance gate
     assert np.array_equal(sg[cg >= 0], so[co >= 0])              # float32 squared distances, bit for bit
-    differ = cg != co
-    assert differ.mean() < 1e-3                                  # only exact-distance ties may pick another index (checked above: equal d2)
-    # a tie resolved the other way swaps one target point (and its covariance) for an equidistant one: each moves the sums by up to
-    # about one term in len(cg)
-    tol = 1e-9 + 10.0 * differ.sum() / len(cg)
+    differ = np.flatnonzero(cg != co)
+    assert len(differ) < 1e-3 * len(cg)                          # only exact-distance ties may pick another index (checked above: equal d2)
+    if len(differ):
+        # A tie resolved the other way swaps one target point (and its covariance) for an equidistant one.  The tolerance is NOT
+        # widened for that: the oracle's sums are re-based onto the GPU's correspondences for exactly those rows (their terms under
+        # the oracle's choice taken out, under the GPU's choice put in), and the comparison stays at 1e-9.
+        Hm, bm, em = _point_terms(src, tgt, cs, ct, differ, co[differ], T)
+        Hp, bp, ep = _point_terms(src, tgt, cs, ct, differ, cg[differ], T)
+        Ho, bo, eo = Ho - Hm + Hp, bo - bm + bp, eo - em + ep
+    print(f"linearisation: {len(differ)} correspondences differ on exact float32 distance ties; |dH|/|H| = {np.abs(Hg - Ho).max() / np.abs(Ho).max():.2e}")
+    tol = 1e-9
     assert abs(eg - eo) <= tol * abs(eo)
-    assert np.abs(Hg - Ho).max() <= tol * np.abs(Ho).max() and np.abs(bg - bo).max() <= tol * np.abs(bo).max(), (int(differ.sum()), np.abs(Hg - Ho).max() / np.abs(Ho).max())
-    return int(differ.sum())
+    assert np.abs(Hg - Ho).max() <= tol * np.abs(Ho).max() and np.abs(bg - bo).max() <= tol * np.abs(bo).max(), (len(differ), np.abs(Hg - Ho).max() / np.abs(Ho).max())
+    return len(differ)
 
 
 def _run_case(ng, orc, w, k, gate, settings, guess, tgt_sizes=None):
@@ -81,7 +102,7 @@ def _run_case(ng, orc, w, k, gate, settings, guess, tgt_sizes=None):
         _check_covs(orc, w.target, tgt_sizes, k, ct)
         g.setTargetCovariances(ct)
     o.setSourceCovariances(cs); o.setTargetCovariances(ct)
-    n_tie0 = _compare_linearisation(g, o, np.asarray(guess, np.float64))
+    n_tie0 = _compare_linearisation(g, o, np.asarray(guess, np.float64), w.source, w.target, cs, ct)
     g.align(guess); o.align(guess)
     Tg, To = g.getFinalTransformation(), o.getFinalTransformation()
     dt, dr = clouds.pose_error(Tg, To)
@@ -98,7 +119,7 @@ def _run_case(ng, orc, w, k, gate, settings, guess, tgt_sizes=None):
         assert np.allclose(tg[:, 2:4], to[:, 2:4], rtol=1e-6)
         cg, _ = g.correspondences(); co, _ = o.correspondences()    # correspondences_ after align(): the last linearisation's
         assert np.array_equal(cg >= 0, co >= 0) and (cg != co).mean() < 1e-3
-    n_tie1 = _compare_linearisation(g, o, Tg.astype(np.float64))   # and at the final pose, distances bit for bit
+    n_tie1 = _compare_linearisation(g, o, Tg.astype(np.float64), w.source, w.target, cs, ct)   # and at the final pose, distances bit for bit
     s = g.stats()
     return dict(dt=dt, dr=dr, ties=(n_tie0, n_tie1), iters=g.nr_iterations_, cand=s["mean_candidates"])
 
@@ -123,6 +144,16 @@ def test_c5_dense_os1_250k_2m(ng, oracle_mod, settings):
     assert len(w.source) == 250_000 and len(w.target) == 2_000_000
     r = _run_case(ng, oracle_mod, w, 20, w.max_corr_dist, settings, w.guess, w.keyframe_sizes)
     print("c5", r)
+
+
+@pytest.mark.parametrize("g_rank", [1, 2, 3, 4, 5, 6, 7])
+def test_c4_seed_offset_workloads_on_one_gpu(ng, oracle_mod, g_rank):
+    """BASELINE configs[3] is one c3-shaped alignment per GPU with seeds offset by 1000 * g (bench.py build_workload); rank 0 is the
+    c3 case above.  No 8-GPU lease exists for the builder, but the seven other WORKLOADS run here, one after the other on one GPU,
+    through the same checks."""
+    w = clouds.scan_to_submap(100_000, 5, seed_offset=1000 * g_rank)
+    r = _run_case(ng, oracle_mod, w, 20, w.max_corr_dist, FIXED20, w.guess, w.keyframe_sizes)
+    print("c4 rank", g_rank, r)
 
 
 def test_source_larger_than_the_sorted_launch_list(ng, oracle_mod):

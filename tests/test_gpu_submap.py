@@ -224,3 +224,19 @@ def test_map_accumulation_and_voxel_filter(ng, oracle_mod):
             assert np.array_equal(g.mapGet(), host)
     g.mapClear()
     assert g.mapSize() == 0 and g.mapGet().shape == (0, 4)
+
+
+def test_map_filter_between_preprocess_and_set_source_is_refused(ng):
+    """The scan filter and the map filter share one workspace: a map publish between preprocessPoints and the hand-over of the
+    filtered scan must not leave the engine indexing freed or foreign memory as its source."""
+    cloud = _raw_scan(20_000)
+    g = ng.NanoGICP()
+    g.preprocessScan(cloud, True, 1.0, 0.25, intensity_col=4)
+    g.mapAdd(np.ascontiguousarray(cloud[np.isfinite(cloud[:, :3]).all(axis=1)][:, [0, 1, 2, 4]]), intensity_col=3)
+    assert g.mapVoxelFilter(0.05) > 0
+    with pytest.raises(ng.NgicpError) as ei:
+        g._ck(g._L.ngicp_set_source_preprocessed(g._h, 0))
+    assert ei.value.code == -3  # NGICP_ERR_STATE (include/ngicp.h)
+    # and the ordinary order still works afterwards
+    filtered = g.preprocessScan(cloud, True, 1.0, 0.25, intensity_col=4, set_as_source=True)
+    assert len(filtered) > 100
