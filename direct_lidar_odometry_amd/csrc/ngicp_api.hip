@@ -90,6 +90,8 @@ struct DeviceCloud {
   float4* pts() const { return sorted.as<float4>() + kSortedPad; }
   DevBuf sorted3;     // Xyz[kSortedPad + n + kSortedPad]: the same points and sentinels, 12 bytes each (the pass kernel's walks)
   Xyz* xyz3() const { return sorted3.as<Xyz>() + kSortedPad; }
+  DevBuf sortedp;     // float4[kSortedPad + n + kSortedPad]: the same points and sentinels, w = sorted position (what the staged pass copies to LDS)
+  float4* xyzp() const { return sortedp.as<float4>() + kSortedPad; }
   DevBuf perm;        // int[n]    sorted position -> original index
   DevBuf inv_perm;    // int[n]    original index -> sorted position (lazily built)
   bool has_inv = false;
@@ -476,6 +478,8 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
                      dc->perm.as<int>());
   dc->sorted3.ensure((n + 2 * kSortedPad) * sizeof(Xyz));
   hipLaunchKernelGGL(k_pack_xyz, dim3((unsigned)((n + 2 * kSortedPad + 255) / 256)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni + 2 * kSortedPad, dc->sorted3.as<Xyz>());
+  dc->sortedp.ensure((n + 2 * kSortedPad) * sizeof(float4));
+  hipLaunchKernelGGL(k_pack_pos, dim3((unsigned)((n + 2 * kSortedPad + 255) / 256)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni + 2 * kSortedPad, kSortedPad, dc->sortedp.as<float4>());
   {
     // query order (Morton over tiles of 2^shift cells; <= 128 tiles per axis => <= 2M histogram bins)
     int shift = 2;
@@ -643,7 +647,20 @@ void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s, hipEve
   // dwords, 4 blocks per CU) for grids of more than two rounds of blocks, where the launch is bound by how many blocks pass through
   // the chip rather than by its slowest block.
   static const int force = std::getenv("NGICP_PASS_WPS") ? std::atoi(std::getenv("NGICP_PASS_WPS")) : 0;  // (A/B timing only)
+  static const int impl = std::getenv("NGICP_PASS_IMPL") ? std::atoi(std::getenv("NGICP_PASS_IMPL")) : 0;  // 0: walks in global memory (default), 1: the staged search of ngicp_pass_st.h (round 3 experiment: exact, slower - DESIGN.md §5)
   const bool four = force ? force == 4 : nblocks > 2 * h->pass_slots;
+  if (impl == 1) {
+    PassArgs b = a;
+    // cells that cover the distance gate around a query's own cell (its reach box is clamped there; beyond it the shell walk takes over)
+    int need = kStGrowMax;
+    if (h->p.max_corr_dist < 1e30) need = (int)std::ceil(h->p.max_corr_dist / (double)a.grid.h);
+    b.stage_grow = std::max(1, std::min(kStGrowMax, need));
+    if (force ? force == 4 : true)  // (128 VGPRs either way; the 4-wave build's smaller tables leave room for a fourth block per CU)
+      hipExtLaunchKernelGGL((k_gicp_pass_st<4>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, b);
+    else
+      hipExtLaunchKernelGGL((k_gicp_pass_st<3>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, b);
+    return;
+  }
   if (four)
     hipExtLaunchKernelGGL((k_gicp_pass<2, 4>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, a);
   else
@@ -689,6 +706,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.n_src = (int)n;
   a.tgt = T.pts();
   a.tgt3 = T.xyz3();
+  a.tgtp = T.xyzp();
   a.tgt_cell_start = T.cells();
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
@@ -856,8 +874,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   }
   const char* qstat_path = std::getenv("NGICP_DEBUG_QSTATS");  // diagnostic only: per-query search statistics of the last pass
   if (qstat_path) {
-    h->dbg_q.ensure((size_t)c.pa.n_src * sizeof(int4));
-    HIP_TRY(hipMemsetAsync(h->dbg_q.p, 0, (size_t)c.pa.n_src * sizeof(int4), h->stream));
+    h->dbg_q.ensure((size_t)c.pa.n_src * 2 * sizeof(int4));
+    HIP_TRY(hipMemsetAsync(h->dbg_q.p, 0, (size_t)c.pa.n_src * 2 * sizeof(int4), h->stream));
     c.pa.dbg_qstats = h->dbg_q.as<int4>();
   }
   const long max_passes = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? (long)h->p.max_iter : (long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1;
@@ -929,7 +947,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     }
   }
   if (qstat_path) {
-    std::vector<int> hq((size_t)c.pa.n_src * 4);
+    std::vector<int> hq((size_t)c.pa.n_src * 8);
     HIP_TRY(hipMemcpy(hq.data(), h->dbg_q.p, hq.size() * sizeof(int), hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(qstat_path, "wb")) {
       std::fwrite(hq.data(), sizeof(int), hq.size(), f);

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_tile_sums(int* __restrict__
 
 // The cell-start table is framed by kCellPad entries on each side (0 in front, the total behind): the four bounds around any cell
 // are then one 16-byte load (see k_gicp_pass).
-constexpr int kCellPad = 4;
+constexpr int kCellPad = 8;  // (k_gicp_pass_st fetches the starts of eight consecutive cells with two 16-byte loads)
 // out[i] = exclusive prefix of counts (out has n + 1 entries; out[n] = total, repeated kCellPad times behind it)
 __global__ void __launch_bounds__(kScanBlock) k_scan_apply(const int* __restrict__ counts, int n, const int* __restrict__ tile_offsets, int* __restrict__ out) {
   __shared__ int lds[8];

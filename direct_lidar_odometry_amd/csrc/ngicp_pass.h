@@ -80,6 +80,15 @@ __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const Xyz&
   return r;
 }
 
+// sorted float4 points (with their sentinel frame) -> the same points carrying their sorted position instead of their original index
+__global__ void __launch_bounds__(256) k_pack_pos(const float4* __restrict__ in, int n_padded, int pad, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_padded) return;
+  const float4 p = in[i];
+  const bool real = i >= pad && i < n_padded - pad;
+  out[i] = make_float4(p.x, p.y, p.z, __int_as_float(real ? i - pad : -1));
+}
+
 // sorted float4 points (with their sentinel frame) -> the packed copy
 __global__ void __launch_bounds__(256) k_pack_xyz(const float4* __restrict__ in, int n, Xyz* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,6 +107,7 @@ struct PassArgs {
   const double* cov_src;    // [n][6], source sorted order
   int n_src;
   const float4* tgt;        // sorted target points
+  const float4* tgtp;       // the same points as {x, y, z, bitcast(sorted position)} (same sentinel frame): what k_gicp_pass_st copies to LDS
   const Xyz* tgt3;          // the same points packed 12 bytes each (same sentinel frame): what the walks and the tail fetch - a quarter
                             // fewer bytes per candidate and three registers per point instead of four
   const int* tgt_cell_start;
@@ -209,8 +219,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // x-gap alone rules the rest out.  Any start is correct (a side only stops once it is past qx AND out of reach); a good
 // start (interpolated from the cell geometry: points of a dense scan line are nearly equidistant in x) makes the cost
 // O(points within reach) with no search at all.  This is what keeps dense scan lines affordable.
-template <int W = kWalkWindow, int kStep = kWalkWindow>
-__device__ __forceinline__ void scan_global_outward(const Xyz* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
+template <int W = kWalkWindow, int kStep = kWalkWindow, class PT>
+__device__ __forceinline__ void scan_global_outward(const PT* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
                                                     float& best, int& pos, unsigned int& ncand, unsigned int& gsteps) {
   if (e <= s) return;
   gsteps += 0x10000u;
@@ -229,8 +239,8 @@ __device__ __forceinline__ void scan_global_outward(const Xyz* __restrict__ tgt,
     // No index clamps: a window that overhangs [s, e) reads points of the neighbouring runs (genuine target points: they can
     // only be legitimate candidates) or the sentinels that frame the array (infinitely far).  The x-gap tests below only
     // look at the window's last / first point when its right / left end is inside the run.
-    const Xyz* __restrict__ q = tgt + w;  // one address, immediate offsets
-    Xyz c[W];
+    const PT* __restrict__ q = tgt + w;  // one address, immediate offsets
+    PT c[W];
 #pragma unroll
     for (int j = 0; j < W; ++j)
       if (j < kStep || wn == W) c[j] = q[j];
@@ -271,8 +281,8 @@ __device__ __forceinline__ void scan_global_outward(const Xyz* __restrict__ tgt,
 // without a memory access; the bounds of the others are fetched in chunks of 4 rows before any row is walked (most shell
 // rows are empty, so a lane pays one memory round trip per chunk instead of one per row); the walks are x-pruned like
 // everywhere else, so a large distance gate costs O(R^2) rows per shell, not O(R^3) points.
-template <int G>
-__device__ __forceinline__ void nn_shells(const Grid& g, const Xyz* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
+template <int G, class PT>
+__device__ __forceinline__ void nn_shells(const Grid& g, const PT* __restrict__ tgt, const int* __restrict__ cell_start, float qx, float qy, float qz,
                                           int cx, int cy, int cz, float gate_sq_f, int sub, int rdone, float& best, int& pos, unsigned int& ncand) {
   const int rmax = max(max(g.nx, g.ny), g.nz);
   unsigned int steps = 0;
@@ -836,6 +846,10 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   if (a.grp_cost && threadIdx.x == 0) a.grp_cost[group] = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
 }
 #undef NG_STAMP
+
+}  // namespace ngk
+#include "ngicp_pass_st.h"
+namespace ngk {
 
 // Upper-triangular packing used by the pass: index of (r,c), r <= c, in the 21-vector
 __host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
