@@ -275,7 +275,7 @@ struct ngicp {
   DevBuf dbg, dbg_q, dbg_s, dbg_span, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
   int order_groups = -1;
-  DevBuf tpt[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums;
+  DevBuf tpt[2], mahal[2], partials, state, trace, tfinal, out_xyz, scratch16, queries, knn_idx, knn_d2, sums, ticket;
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_progress = nullptr;  // pinned: {passes done | kProgressDone}, written by the solver (SolveArgs::progress_host)
   LmState* pin_state = nullptr;  // pinned [2]: the state image an align uploads / the one it reads back (no staging copies)
@@ -642,15 +642,21 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
 // ------------------------------------------------------------------------------------------
 // start / stop: events attached to the dispatch itself (they take the kernel's own begin / end timestamps: no extra packets in
 // the stream, unlike hipEventRecord before and after), or null
+int pass_impl() {
+  static const int impl = std::getenv("NGICP_PASS_IMPL") ? std::atoi(std::getenv("NGICP_PASS_IMPL")) : 0;
+  return impl;
+}
+
 void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
   // 32-query batches, 2 lanes per query.  Two builds of the kernel: 3 waves per SIMD (129 VGPRs), and 4 (128 VGPRs, two spilled
   // dwords, 4 blocks per CU) for grids of more than two rounds of blocks, where the launch is bound by how many blocks pass through
   // the chip rather than by its slowest block.
   static const int force = std::getenv("NGICP_PASS_WPS") ? std::atoi(std::getenv("NGICP_PASS_WPS")) : 0;  // (A/B timing only)
-  static const int impl = std::getenv("NGICP_PASS_IMPL") ? std::atoi(std::getenv("NGICP_PASS_IMPL")) : 0;  // 0: walks in global memory (default), 1: the staged search of ngicp_pass_st.h (round 3 experiment: exact, slower - DESIGN.md §5)
+  const int impl = pass_impl();  // 0: walks in global memory (default), 1: the staged search of ngicp_pass_st.h (round 3 experiment: exact, slower - DESIGN.md §5)
   const bool four = force ? force == 4 : nblocks > 2 * h->pass_slots;
   if (impl == 1) {
     PassArgs b = a;
+    b.fused = 0;
     // cells that cover the distance gate around a query's own cell (its reach box is clamped there; beyond it the shell walk takes over)
     int need = kStGrowMax;
     if (h->p.max_corr_dist < 1e30) need = (int)std::ceil(h->p.max_corr_dist / (double)a.grid.h);
@@ -728,6 +734,9 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.dbg_stamps = nullptr;
   a.dbg_qstats = nullptr;
   a.dbg_span = nullptr;
+  a.fused = 0;
+  h->ticket.ensure(64);
+  a.ticket = h->ticket.as<int>();
   {
     // rings worth staging: enough to cover the distance gate (the search never looks farther), at most kStageMaxGrow
     int need = kStageMaxGrow;
@@ -886,6 +895,16 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   const int depth = h->chunk_pairs;
   *h->h_progress = 0;
   c.sa.progress_host = h->h_progress;
+  // NGICP_FUSED=1: one dispatch per iteration - the last block of the pass reduces and advances the optimiser (PassArgs::fused).
+  // Measured on MI355X (round 3, profiles/r03_fused_solver.txt): bit-identical results, but no faster than the separate launch (c3
+  // 46.3 vs 45.4 us per iteration, c5 70 vs 56): the write-through rows come back from memory, not from L2, through ONE CU
+  // (8.7 k cycles for 222 KB against 5.5 k in k_lm_solve), plus the acquire (~1.7 us) - so the default stays two launches.
+  static const bool fused_env = std::getenv("NGICP_FUSED") && std::atoi(std::getenv("NGICP_FUSED")) != 0;
+  if (fused_env && pass_impl() == 0) {
+    c.pa.fused = 1;
+    c.pa.sa = c.sa;
+    HIP_TRY(hipMemsetAsync(h->ticket.p, 0, 64, h->stream));
+  }
   HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   long launched = 0;
   bool finished = (h->p.max_iter <= 0);
@@ -901,7 +920,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     }
     const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
     launch_pass(h, c.pa, c.nblocks, h->stream, timed ? h->prof_events[2 * launched] : nullptr, timed ? h->prof_events[2 * launched + 1] : nullptr);
-    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
+    if (!c.pa.fused) hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     ++launched;
   }
   HIP_TRY(hipEventRecord(h->ev_b, h->stream));

@@ -97,6 +97,21 @@ __global__ void __launch_bounds__(256) k_pack_xyz(const float4* __restrict__ in,
   out[i] = Xyz{p.x, p.y, p.z};
 }
 
+struct SolveArgs {
+  LmState* st;
+  LmConfig cfg;
+  const double* partials;  // [nblocks][kNumSlots] group-major (nblocks == 1: one pre-reduced vector)
+  int nblocks;
+  double* trace;           // [max_rows][8]
+  int max_trace_rows;
+  int mode;                // 0: LM/GN state machine; 1: reduce -> H/b/y0 (linearize hook); 2: reduce -> y0 = yi (error hook); 3: reduce only
+  double* sums_out;        // optional [kPartialStride] reduced sums (29 sums + 2 counters + 1 pad)
+  int* grp_order;          // [nblocks] out: groups sorted by measured cost, heaviest first (mode 0 only), or null
+  const int* grp_cost;     // [nblocks] in: duration of each group's block in the pass just finished
+  unsigned long long* dbg_stamps;  // diagnostic only: [8] s_memtime stamps of the last launch, or null
+  int* progress_host;      // pinned host memory, or null: {passes done | kProgressDone} published after every step (mode 0)
+};
+
 struct PassArgs {
   const float4* qpts;       // source points in Morton-tile query order, w = sorted source position
   const int2* batches;      // tile-aligned query batches {first qpts index, count <= 32}
@@ -127,6 +142,11 @@ struct PassArgs {
   unsigned long long* dbg_stamps;  // diagnostic only: [wave][kStampStride] s_memtime stamps + counters, or null
   int4* dbg_qstats;                // diagnostic only: per query {ring-1 candidates, ring-1 walks | far walks << 16, far + shell candidates, flags}, or null
   unsigned long long* dbg_span;    // diagnostic only: per block {s_memrealtime (10 ns ticks) at entry, at exit, HW_ID | XCC_ID << 32, group}, or null
+  // fused solver: the block whose ticket is the last of the grid reduces the group rows and advances the optimiser in the tail of
+  // the SAME launch (no second dispatch per iteration).  Rows and costs are then stored write-through and published by the ticket.
+  int fused;
+  int* ticket;   // zero before the launch; the last block puts it back
+  SolveArgs sa;
 };
 
 // --- cooperative exact 1-NN ------------------------------------------------------------------
@@ -336,6 +356,441 @@ __device__ __forceinline__ void nn_shells(const Grid& g, const PT* __restrict__ 
   }
 }
 
+
+// Upper-triangular packing used by the pass: index of (r,c), r <= c, in the 21-vector
+__host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+// --- the solver ----------------------------------------------------------------------------------
+constexpr int kMaxOrderGroups = 4096;  // launch-order sort: groups whose costs fit the solver's LDS and one load round (8 per thread)
+constexpr int kSolveThreads = 512;  // 8 waves = 2 per SIMD: the serial lane keeps a 256-VGPR budget, the reduction gets 512 loaders
+constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (thread = 16 slot pairs x 32 group subsets)
+#ifndef NGICP_SOLVE_CHUNK
+#define NGICP_SOLVE_CHUNK 40
+#endif
+constexpr int kSolveChunk = NGICP_SOLVE_CHUNK;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 40 = 1280 groups
+
+constexpr int kProgressDone = 1 << 30, kProgressMask = kProgressDone - 1;
+
+__device__ __forceinline__ bool is_converged_dev(const Pose& d, double rot_eps, double trans_eps) {  // impl/lsq_registration_impl.hpp:118-127
+  double rmax = 0.0, tmax = 0.0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rmax = fmax(rmax, 1.0 / rot_eps * fabs(d.R[r * 3 + c] - (r == c ? 1.0 : 0.0)));
+    tmax = fmax(tmax, 1.0 / trans_eps * fabs(d.t[r]));
+  }
+  return fmax(rmax, tmax) < 1;
+}
+
+// d = (H + lambda I)^-1 (-b); delta = (so3_exp(d[0:3]), d[3:6]); xi = delta * x0
+__device__ __forceinline__ void make_trial(LmHot& L, double lambda_add) {
+  double A[36], rhs[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) A[i] = L.H[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    A[i * 6 + i] += lambda_add;
+    rhs[i] = -L.b[i];
+  }
+  ldlt6_solve(A, rhs, L.d);
+  pose_identity(L.delta);
+  so3_exp_matrix(L.d, L.delta.R);
+  L.delta.t[0] = L.d[3];
+  L.delta.t[1] = L.d[4];
+  L.delta.t[2] = L.d[5];
+  pose_mul(L.delta, L.x0, L.xi);
+}
+
+// new linearisation (reduced sums in LDS) becomes current
+__device__ __forceinline__ void adopt_new(LmHot& L, const double* sums) {
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) L.H[r * 6 + c] = L.H[c * 6 + r] = sums[tri21(r, c)];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) L.b[i] = sums[21 + i];
+  L.y0 = sums[27];
+  L.cur ^= 1;
+  L.have_lin = 1;
+}
+
+// One step of LsqRegistration's optimiser on the register-resident state.  Returns true when H was
+// accepted as final_hessian_ (impl/lsq_registration_impl.hpp:155,203).
+__device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const double* sums, double* trace, int max_trace_rows) {
+  const double yi = sums[28];
+  L.passes += 1;
+  L.cand_total += sums[29];
+  L.valid_total += sums[30];
+  L.staged_total += sums[31];
+
+  if (cfg.optimizer == 0) {
+    // ---- Gauss-Newton: impl/lsq_registration_impl.hpp:142-158, one pass per outer iteration ----
+    adopt_new(L, sums);
+    L.nr_iterations = L.iter;
+    make_trial(L, 0.0);
+    L.x0 = L.xi;
+    L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
+    L.iter += 1;
+    if (L.converged || L.iter >= cfg.max_iterations) L.done = 1;
+    return true;
+  }
+
+  // ---- Levenberg-Marquardt: impl/lsq_registration_impl.hpp:161-208 ----
+  if (!L.have_lin) {
+    // first pass: linearisation at the initial guess
+    adopt_new(L, sums);
+    L.nr_iterations = 0;
+    if (L.lambda < 0.0) {
+      double m = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m = fmax(m, fabs(L.H[i * 6 + i]));
+      L.lambda = cfg.lm_init_lambda_factor * m;
+    }
+    L.nu = 2.0;
+    L.trial = 0;
+    if (cfg.lm_max_iterations <= 0) {  // the reference's inner loop would not run: "lm not converged"
+      L.lm_failed = 1;
+      L.done = 1;
+      return false;
+    }
+    make_trial(L, L.lambda);
+    return false;
+  }
+
+  double den = 0.0, dn = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
+    dn += L.d[i] * L.d[i];
+  }
+  const double rho = (L.y0 - yi) / den;
+  const bool rejected = rho < 0;  // NaN is accepted, as upstream
+  if (trace && L.n_trace < max_trace_rows) {
+    double* row = trace + (size_t)L.n_trace * kTraceCols;
+    row[0] = L.iter; row[1] = L.trial; row[2] = L.y0; row[3] = yi;
+    row[4] = rho; row[5] = L.lambda; row[6] = sqrt(dn); row[7] = rejected ? 0.0 : 1.0;
+    L.n_trace += 1;
+  }
+  if (rejected) {
+    if (is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps)) {  // :191-194 — x0 stays, step reports success
+      L.converged = 1;
+      L.done = 1;
+      return false;
+    }
+    L.lambda = L.nu * L.lambda;
+    L.nu = 2 * L.nu;
+    L.trial += 1;
+    if (L.trial >= cfg.lm_max_iterations) {  // :207 -> "lm not converged!!", break (:105-108)
+      L.lm_failed = 1;
+      L.converged = 0;
+      L.done = 1;
+      return false;
+    }
+    make_trial(L, L.lambda);
+    return false;
+  }
+  // accepted (:201-204); final_hessian_ = H is written by the caller BEFORE the state is advanced
+  return true;
+}
+
+// The solver's block-shared scratch.  k_lm_solve owns one; the fused tail of k_gicp_pass lays it over the (then idle) search tables.
+template <int THREADS>
+struct SolveShared {
+  double wsum[32][kPartialStride];
+  double sums[kPartialStride];
+  int ord_cnt[THREADS / 64 - 1][16], ord_pos[THREADS / 64 - 1][16];  // per sorting wave and cost class
+  int ord_cost[kMaxOrderGroups];
+  unsigned char ord_cls[kMaxOrderGroups];
+  int ord_arrived;
+  LmHot L;
+};
+
+// The body of the solver for a block of THREADS threads (512: k_lm_solve; 256: the last block of a fused pass).  AGENT: the group rows
+// and costs were written by other blocks of the SAME launch (write-through stores, published by a ticket; the caller has run the
+// agent-scope acquire): they are then read with agent-scope loads, which bypass this CU's L1 whatever it holds.
+template <int THREADS, bool AGENT>
+__device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<THREADS>& sh) {
+  constexpr int kSolveThreads = THREADS;
+  constexpr int kSolveSubs = 32;                      // subsets of rows (row g belongs to subset g mod 32), whatever the block size
+  constexpr int kThreadSubs = THREADS / 16;           // subsets the block's threads cover at once
+  constexpr int kPer = kSolveSubs / kThreadSubs;      // subsets per thread (512 threads: 1, 256 threads: 2)
+  constexpr int kSolveChunk = THREADS >= 512 ? NGICP_SOLVE_CHUNK : 14;  // 16-byte loads per subset a thread keeps in flight per step (4 VGPRs each; the fused block has the pass kernel's 168-register budget)
+  static_assert(kPer >= 1 && kPer * kThreadSubs == kSolveSubs, "block sizes: 256 or 512 threads");
+  auto& wsum = sh.wsum;
+  auto& sums = sh.sums;
+  auto& ord_cnt = sh.ord_cnt;
+  auto& ord_pos = sh.ord_pos;
+  auto& ord_cost = sh.ord_cost;
+  auto& ord_cls = sh.ord_cls;
+  int& ord_arrived = sh.ord_arrived;
+  LmHot& L = sh.L;
+  if (threadIdx.x == 0) ord_arrived = 0;  // (visible to every wave after the barriers below)
+  LmState* st = a.st;
+#define NG_SSTAMP(k)                                                                 \
+  do {                                                                               \
+    if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+  const int done_at_entry = st->hot.done;
+  if (a.dbg_stamps && threadIdx.x == 0 && !done_at_entry) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
+  // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
+  //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
+  //      covers 1280 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
+  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass. ----
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
+  const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
+  // Everything the block needs from memory is requested HERE, before the first wait: the state image the serial lane will work on
+  // (fetched by the whole block, one coalesced access, instead of by lane 0 after the reduction), the first step of group rows, the
+  // groups' measured costs.  Consumed one after the other they were three dependent round trips of ~0.9 us each.
+  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
+  constexpr int kHotWords = (int)(sizeof(LmHot) / 4), kHotPerThread = (kHotWords + kSolveThreads - 1) / kSolveThreads;
+  constexpr int kCostPerThread = kMaxOrderGroups / kSolveThreads;
+  // (the fused block has three sorting waves instead of seven: the order is refreshed after the first three passes of an alignment -
+  // the costs settle with the warm start - and after every fourth from then on, so that it stays off the serial lane's path)
+  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups && (!AGENT || st->hot.passes < 3 || (st->hot.passes & 3) == 3);
+  int hv[kHotPerThread];
+#pragma unroll
+  for (int k = 0; k < kHotPerThread; ++k) {
+    const int w = threadIdx.x + k * kSolveThreads;
+    hv[k] = w < kHotWords ? reinterpret_cast<const int*>(&st->hot)[w] : 0;
+  }
+  // (One CU moves 64 B per clock: the 222 KB of 866 rows are ~3.5k cycles on top of the latency.  Rows beyond the grid are skipped by
+  // a branch each: fetching a stand-in row instead - branch-free issue - measured slower, the stand-ins pile up on one channel.)
+  const int last_row = a.nblocks - 1;
+  // (AGENT: the caller's agent-scope acquire has dropped this CU's L1, the producers stored write-through and no line of these rows
+  // can be in this XCD's L2 from before - nobody read them earlier in this launch: plain 16-byte loads, as MI355X_MICROARCH.md's
+  // "valid forms" prescribe for the consumer side)
+  auto load_row = [](const double2* q) -> double2 { return *q; };
+  // (The order of the sums never depends on the block size: 32 subsets of rows; a thread of a 256-thread block takes two of them.)
+  double2 p[kPer * kSolveChunk];
+#pragma unroll
+  for (int sI = 0; sI < kPer; ++sI)
+#pragma unroll
+    for (int j = 0; j < kSolveChunk; ++j) {
+      const int gi = sb + sI * kThreadSubs + j * kSolveSubs;
+      p[sI * kSolveChunk + j] = gi <= last_row ? load_row(rows + (size_t)gi * (kNumSlots / 2)) : make_double2(0.0, 0.0);
+    }
+  int oc[kCostPerThread];
+#pragma unroll
+  for (int k = 0; k < kCostPerThread; ++k) {
+    const int gi = threadIdx.x + k * kSolveThreads;
+    oc[k] = (order_it && gi <= last_row) ? a.grp_cost[gi] : 0;
+  }
+  if (a.mode == 0 && done_at_entry) return;  // (a scalar load issued at the top: it does not wait for the vector loads above)
+  // The serial lane works on the LDS image of the state in place (a register-resident copy needs ~260 VGPRs: it spills at two
+  // waves per SIMD), and wave 0 stores it back with one coalesced pass.
+#pragma unroll
+  for (int k = 0; k < kHotPerThread; ++k) {
+    const int w = threadIdx.x + k * kSolveThreads;
+    if (w < kHotWords) reinterpret_cast<int*>(&L)[w] = hv[k];
+  }
+  if (order_it) {  // the groups' costs, for the launch order built further down (visible after the barriers below)
+#pragma unroll
+    for (int k = 0; k < kCostPerThread; ++k) {
+      const int gi = threadIdx.x + k * kSolveThreads;
+      if (gi < a.nblocks) ord_cost[gi] = oc[k];
+    }
+  }
+  {
+    double a0[kPer], a1[kPer];
+#pragma unroll
+    for (int sI = 0; sI < kPer; ++sI) {
+      a0[sI] = p[sI * kSolveChunk].x;  // (not 0.0 + p[0]: the compiler places that add, and a wait for the first load alone, before the other loads)
+      a1[sI] = p[sI * kSolveChunk].y;
+#pragma unroll
+      for (int j = 1; j < kSolveChunk; ++j) {
+        a0[sI] += p[sI * kSolveChunk + j].x;
+        a1[sI] += p[sI * kSolveChunk + j].y;
+      }
+    }
+    for (int g0 = kSolveSubs * kSolveChunk; g0 + sb <= last_row; g0 += kSolveSubs * kSolveChunk) {  // larger grids: further steps
+#pragma unroll
+      for (int sI = 0; sI < kPer; ++sI)
+#pragma unroll
+        for (int j = 0; j < kSolveChunk; ++j) {
+          const int gi = g0 + sb + sI * kThreadSubs + j * kSolveSubs;
+          p[sI * kSolveChunk + j] = gi <= last_row ? load_row(rows + (size_t)gi * (kNumSlots / 2)) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+      for (int sI = 0; sI < kPer; ++sI)
+#pragma unroll
+        for (int j = 0; j < kSolveChunk; ++j) {
+          a0[sI] += p[sI * kSolveChunk + j].x;
+          a1[sI] += p[sI * kSolveChunk + j].y;
+        }
+    }
+    NG_SSTAMP(1);
+#pragma unroll
+    for (int sI = 0; sI < kPer; ++sI) {
+      wsum[sb + sI * kThreadSubs][2 * vp] = a0[sI];
+      wsum[sb + sI * kThreadSubs][2 * vp + 1] = a1[sI];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kPartialStride) {
+    const int v = threadIdx.x;
+    double t = 0.0;
+    if (v < kNumSlots)
+      for (int sb = 0; sb < kSolveSubs; ++sb) t += wsum[sb][v];
+    sums[v] = t;
+  }
+  __syncthreads();
+  NG_SSTAMP(2);
+  if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
+  if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
+  if (order_it && wave >= 1) {
+    const unsigned long long t_ord = a.dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    // ---- launch order of the next pass, built by waves 1..7 (costs already in LDS) while lane 0 of wave 0 runs the state machine:
+    //      a counting sort into 16 cost classes relative to the slowest group, heaviest class first, ascending group index inside
+    //      a class.  (The pass's results do not depend on the launch order.) ----
+    // A lone wave is bound by the latency of its own LDS round trips (~600 cycles per 64 groups and loop: 7 us for 866 groups, 17 us
+    // for 2217 - longer than the state machine), so every wave sorts a contiguous SLICE of the groups: it counts its slice per class,
+    // the seven waves meet at a counter in LDS (all waves of a block are resident: the wait cannot deadlock, and it is bounded), and
+    // each then knows where its slice starts inside every class.  No per-lane atomics and no per-class loops: four ballots (one per
+    // bit of the class) give every lane the mask of the lanes that share its class; its rank is a popcount, and the lowest lane of
+    // each class moves the class's counter in LDS (distinct addresses per class; same-wave LDS operations are ordered).
+    constexpr int kSortWaves = kSolveThreads / 64 - 1;
+    const int sw = wave - 1;
+    auto wsync = [] {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto same_class = [&](int cls, bool valid) -> unsigned long long {
+      unsigned long long m = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const bool one = (cls >> bit) & 1;
+        const unsigned long long bb = __ballot(valid && one);
+        m &= one ? bb : ~bb;
+      }
+      return m;
+    };
+    if (lane < 16) ord_cnt[sw][lane] = 0;
+    int mx = 1;  // (every wave looks at all the costs: no exchange needed for the maximum)
+    for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, ord_cost[gi]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    const float to_class = 16.0f / ((float)mx + 1.0f);  // (a heuristic: float rounding at class boundaries is immaterial)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int slice = ((a.nblocks + kSortWaves * 64 - 1) / (kSortWaves * 64)) * 64;  // groups per wave, a multiple of 64
+    const int g_first = sw * slice, g_last = min(g_first + slice, a.nblocks);
+    wsync();
+    for (int g0 = g_first; g0 < g_last; g0 += 64) {
+      const int gi = g0 + lane;
+      const bool valid = gi < g_last;
+      const int cls = valid ? 15 - min(15, (int)((float)ord_cost[gi] * to_class)) : 0;
+      if (valid) ord_cls[gi] = (unsigned char)cls;
+      const unsigned long long m = same_class(cls, valid);
+      if (valid && (m & lt) == 0) ord_cnt[sw][cls] += __popcll(m);  // the class's lowest lane
+      wsync();
+    }
+    // the seven waves meet
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) atomicAdd(&ord_arrived, 1);
+    bool met = false;
+    for (int spin = 0; spin < (1 << 20); ++spin) {
+      if (*reinterpret_cast<volatile int*>(&ord_arrived) >= kSortWaves) {
+        met = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (met) {  // (never false in practice; the order of the previous refresh then simply stays)
+      if (lane < 16) {  // where this wave's slice starts inside class `lane`
+        int run = 0;
+        for (int c = 0; c < lane; ++c)
+          for (int w = 0; w < kSortWaves; ++w) run += ord_cnt[w][c];
+        for (int w = 0; w < sw; ++w) run += ord_cnt[w][lane];
+        ord_pos[sw][lane] = run;
+      }
+      wsync();
+      for (int g0 = g_first; g0 < g_last; g0 += 64) {
+        const int gi = g0 + lane;
+        const bool valid = gi < g_last;
+        const int cls = valid ? ord_cls[gi] : 0;
+        const unsigned long long m = same_class(cls, valid);
+        const int base = ord_pos[sw][cls];
+        if (valid) a.grp_order[base + __popcll(m & lt)] = gi;  // within a class: ascending group index
+        wsync();
+        if (valid && (m & lt) == 0) ord_pos[sw][cls] = base + __popcll(m);
+        wsync();
+      }
+      if (sw == 0 && lane == 0) st->order_valid = 1;
+    }
+    if (a.dbg_stamps && sw == 0 && lane == 0) a.dbg_stamps[7] = __builtin_amdgcn_s_memtime() - t_ord;
+  }
+  if (wave != 0) return;
+  if (a.mode == 2) {  // compute_error hook
+    if (lane == 0) st->hot.y0 = sums[28];
+    return;
+  }
+  if (lane == 0) {
+    if (a.mode == 1) {  // linearize hook
+      adopt_new(L, sums);
+    } else {
+      const LmConfig& cfg = a.cfg;
+      const bool gn = cfg.optimizer == 0;
+      NG_SSTAMP(3);
+      const bool accepted = lm_advance(L, cfg, sums, a.trace, a.max_trace_rows);
+      NG_SSTAMP(4);
+      if (accepted) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) st->final_hessian[i] = L.H[i];
+        if (!gn) {
+          // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
+          double den = 0.0;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
+          const double rho = (L.y0 - sums[28]) / den;
+          L.x0 = L.xi;
+          const double q = 2 * rho - 1;
+          L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - q * q * q);
+          L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
+          L.iter += 1;
+          if (L.converged || L.iter >= cfg.max_iterations) {
+            L.done = 1;
+          } else {
+            // the speculative linearisation at xi (== new x0) becomes current
+            adopt_new(L, sums);
+            L.nr_iterations = L.iter;
+            L.nu = 2.0;
+            L.trial = 0;
+            make_trial(L, L.lambda);
+          }
+        }
+      }
+      NG_SSTAMP(5);
+      if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
+      if (!L.done) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) st->xi_f[r * 4 + c] = (float)L.xi.R[r * 3 + c];
+          st->xi_f[r * 4 + 3] = (float)L.xi.t[r];
+        }
+      }
+    }
+  }
+  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag);
+  // issued before the state goes back so that the PCIe write overlaps it
+  if (a.mode == 0 && a.progress_host && lane == 0)
+    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // wave 0 stores the state image back (lane 0's LDS writes are ordered before the other lanes' reads by the fence pair)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
+  NG_SSTAMP(6);
+#undef NG_SSTAMP
+}
+
+__global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
+  __shared__ SolveShared<kSolveThreads> sh;
+  lm_solve_body<kSolveThreads, false>(a, sh);
+}
+
 constexpr int kStampStride = 24;
 #define NG_STAMP(k)                                                                                   \
   do {                                                                                                \
@@ -352,7 +807,13 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   static_assert(kWin <= kSortedPad, "walk windows may overhang the array by at most the sentinel frame");
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
-  __shared__ WaveStage stage_all[4];
+  union PassShared {
+    WaveStage stage[4];
+    SolveShared<256> sv;  // the fused solver (the last block of the grid) works where the search tables were
+  };
+  __shared__ PassShared shm;
+  __shared__ int last_block;
+  WaveStage* stage_all = shm.stage;
   const LmState* __restrict__ st = a.st;
   if (!(a.mode & 4) && st->hot.done) return;
 
@@ -835,7 +1296,10 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   NG_STAMP(9);
   if (threadIdx.x < kNumSlots) {
     const int v = threadIdx.x;
-    a.partials[(size_t)group * kNumSlots + v] = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
+    const double val = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
+    // fused: write-through (agent-scope store: nothing stays dirty in this XCD's L2, no release fence and no L2 write-back needed)
+    if (a.fused) __hip_atomic_store(a.partials + (size_t)group * kNumSlots + v, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.partials[(size_t)group * kNumSlots + v] = val;
   }
   if (a.dbg_span && threadIdx.x == 0) {
     unsigned long long* d = a.dbg_span + (size_t)blockIdx.x * 4;
@@ -843,412 +1307,42 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
     d[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
     d[3] = (unsigned long long)(unsigned int)group;
   }
-  if (a.grp_cost && threadIdx.x == 0) a.grp_cost[group] = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
+  if (a.grp_cost && threadIdx.x == 0) {
+    const int cost = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
+    if (a.fused) __hip_atomic_store(a.grp_cost + group, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else a.grp_cost[group] = cost;
+  }
+  if (!a.fused) return;
+  // ---- the solver in the tail of the launch (R0's final sum, impl/nano_gicp_impl.hpp:260-267, and LsqRegistration's step,
+  //      impl/lsq_registration_impl.hpp:161-208).  Every store of this block that another block will read was made by wave 0 as a
+  //      write-through store; wave 0 drains them, then ONE lane takes a ticket (relaxed, agent scope).  The block that draws the
+  //      last ticket of the grid knows that every other block's rows are in memory: one agent-scope acquire (drops this CU's L1;
+  //      no other block pays anything), then it reads the rows with agent-scope loads, reduces them in the fixed group order and
+  //      advances the optimiser exactly as k_lm_solve does.  (Round 2's version released with a fence per block: an agent-scope
+  //      release writes the XCD's whole dirty L2 back - the pass's own 6 MB of outputs, once per block: 36 -> 143 us.) ----
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const int tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_block = (tk == (int)gridDim.x - 1) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (!last_block) return;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch: ordered by the kernel boundary)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  lm_solve_body<256, true>(a.sa, shm.sv);
 }
 #undef NG_STAMP
+
 
 }  // namespace ngk
 #include "ngicp_pass_st.h"
 namespace ngk {
-
-// Upper-triangular packing used by the pass: index of (r,c), r <= c, in the 21-vector
-__host__ __device__ __forceinline__ int tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
-
-// --- the solver ----------------------------------------------------------------------------------
-constexpr int kMaxOrderGroups = 4096;  // launch-order sort: groups whose costs fit the solver's LDS and one load round (8 per thread)
-constexpr int kSolveThreads = 512;  // 8 waves = 2 per SIMD: the serial lane keeps a 256-VGPR budget, the reduction gets 512 loaders
-constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (thread = 16 slot pairs x 32 group subsets)
-#ifndef NGICP_SOLVE_CHUNK
-#define NGICP_SOLVE_CHUNK 40
-#endif
-constexpr int kSolveChunk = NGICP_SOLVE_CHUNK;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 40 = 1280 groups
-
-struct SolveArgs {
-  LmState* st;
-  LmConfig cfg;
-  const double* partials;  // [nblocks][kNumSlots] group-major (nblocks == 1: one pre-reduced vector)
-  int nblocks;
-  double* trace;           // [max_rows][8]
-  int max_trace_rows;
-  int mode;                // 0: LM/GN state machine; 1: reduce -> H/b/y0 (linearize hook); 2: reduce -> y0 = yi (error hook); 3: reduce only
-  double* sums_out;        // optional [kPartialStride] reduced sums (29 sums + 2 counters + 1 pad)
-  int* grp_order;          // [nblocks] out: groups sorted by measured cost, heaviest first (mode 0 only), or null
-  const int* grp_cost;     // [nblocks] in: duration of each group's block in the pass just finished
-  unsigned long long* dbg_stamps;  // diagnostic only: [8] s_memtime stamps of the last launch, or null
-  int* progress_host;      // pinned host memory, or null: {passes done | kProgressDone} published after every step (mode 0)
-};
-constexpr int kProgressDone = 1 << 30, kProgressMask = kProgressDone - 1;
-
-__device__ __forceinline__ bool is_converged_dev(const Pose& d, double rot_eps, double trans_eps) {  // impl/lsq_registration_impl.hpp:118-127
-  double rmax = 0.0, tmax = 0.0;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) rmax = fmax(rmax, 1.0 / rot_eps * fabs(d.R[r * 3 + c] - (r == c ? 1.0 : 0.0)));
-    tmax = fmax(tmax, 1.0 / trans_eps * fabs(d.t[r]));
-  }
-  return fmax(rmax, tmax) < 1;
-}
-
-// d = (H + lambda I)^-1 (-b); delta = (so3_exp(d[0:3]), d[3:6]); xi = delta * x0
-__device__ __forceinline__ void make_trial(LmHot& L, double lambda_add) {
-  double A[36], rhs[6];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) A[i] = L.H[i];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    A[i * 6 + i] += lambda_add;
-    rhs[i] = -L.b[i];
-  }
-  ldlt6_solve(A, rhs, L.d);
-  pose_identity(L.delta);
-  so3_exp_matrix(L.d, L.delta.R);
-  L.delta.t[0] = L.d[3];
-  L.delta.t[1] = L.d[4];
-  L.delta.t[2] = L.d[5];
-  pose_mul(L.delta, L.x0, L.xi);
-}
-
-// new linearisation (reduced sums in LDS) becomes current
-__device__ __forceinline__ void adopt_new(LmHot& L, const double* sums) {
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = r; c < 6; ++c) L.H[r * 6 + c] = L.H[c * 6 + r] = sums[tri21(r, c)];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) L.b[i] = sums[21 + i];
-  L.y0 = sums[27];
-  L.cur ^= 1;
-  L.have_lin = 1;
-}
-
-// One step of LsqRegistration's optimiser on the register-resident state.  Returns true when H was
-// accepted as final_hessian_ (impl/lsq_registration_impl.hpp:155,203).
-__device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const double* sums, double* trace, int max_trace_rows) {
-  const double yi = sums[28];
-  L.passes += 1;
-  L.cand_total += sums[29];
-  L.valid_total += sums[30];
-  L.staged_total += sums[31];
-
-  if (cfg.optimizer == 0) {
-    // ---- Gauss-Newton: impl/lsq_registration_impl.hpp:142-158, one pass per outer iteration ----
-    adopt_new(L, sums);
-    L.nr_iterations = L.iter;
-    make_trial(L, 0.0);
-    L.x0 = L.xi;
-    L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
-    L.iter += 1;
-    if (L.converged || L.iter >= cfg.max_iterations) L.done = 1;
-    return true;
-  }
-
-  // ---- Levenberg-Marquardt: impl/lsq_registration_impl.hpp:161-208 ----
-  if (!L.have_lin) {
-    // first pass: linearisation at the initial guess
-    adopt_new(L, sums);
-    L.nr_iterations = 0;
-    if (L.lambda < 0.0) {
-      double m = 0.0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) m = fmax(m, fabs(L.H[i * 6 + i]));
-      L.lambda = cfg.lm_init_lambda_factor * m;
-    }
-    L.nu = 2.0;
-    L.trial = 0;
-    if (cfg.lm_max_iterations <= 0) {  // the reference's inner loop would not run: "lm not converged"
-      L.lm_failed = 1;
-      L.done = 1;
-      return false;
-    }
-    make_trial(L, L.lambda);
-    return false;
-  }
-
-  double den = 0.0, dn = 0.0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
-    dn += L.d[i] * L.d[i];
-  }
-  const double rho = (L.y0 - yi) / den;
-  const bool rejected = rho < 0;  // NaN is accepted, as upstream
-  if (trace && L.n_trace < max_trace_rows) {
-    double* row = trace + (size_t)L.n_trace * kTraceCols;
-    row[0] = L.iter; row[1] = L.trial; row[2] = L.y0; row[3] = yi;
-    row[4] = rho; row[5] = L.lambda; row[6] = sqrt(dn); row[7] = rejected ? 0.0 : 1.0;
-    L.n_trace += 1;
-  }
-  if (rejected) {
-    if (is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps)) {  // :191-194 — x0 stays, step reports success
-      L.converged = 1;
-      L.done = 1;
-      return false;
-    }
-    L.lambda = L.nu * L.lambda;
-    L.nu = 2 * L.nu;
-    L.trial += 1;
-    if (L.trial >= cfg.lm_max_iterations) {  // :207 -> "lm not converged!!", break (:105-108)
-      L.lm_failed = 1;
-      L.converged = 0;
-      L.done = 1;
-      return false;
-    }
-    make_trial(L, L.lambda);
-    return false;
-  }
-  // accepted (:201-204); final_hessian_ = H is written by the caller BEFORE the state is advanced
-  return true;
-}
-
-__global__ void __launch_bounds__(kSolveThreads) k_lm_solve(SolveArgs a) {
-  __shared__ double wsum[kSolveSubs][kPartialStride];
-  __shared__ double sums[kPartialStride];
-  __shared__ int ord_cnt[kSolveThreads / 64 - 1][16], ord_pos[kSolveThreads / 64 - 1][16];  // per sorting wave and cost class
-  __shared__ int ord_cost[kMaxOrderGroups];
-  __shared__ unsigned char ord_cls[kMaxOrderGroups];
-  __shared__ int ord_arrived;
-  if (threadIdx.x == 0) ord_arrived = 0;  // (visible to every wave after the barriers below)
-  LmState* st = a.st;
-#define NG_SSTAMP(k)                                                                 \
-  do {                                                                               \
-    if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-  const int done_at_entry = st->hot.done;
-  if (a.dbg_stamps && threadIdx.x == 0 && !done_at_entry) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
-  // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
-  //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
-  //      covers 1280 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
-  //      in subset order.  Fixed order throughout: bit-reproducible, independent of the launch order of the pass. ----
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int vp = threadIdx.x & 15, sb = threadIdx.x >> 4;
-  const double2* __restrict__ rows = reinterpret_cast<const double2*>(a.partials) + vp;  // row g: rows[g * 16]
-  // Everything the block needs from memory is requested HERE, before the first wait: the state image the serial lane will work on
-  // (fetched by the whole block, one coalesced access, instead of by lane 0 after the reduction), the first step of group rows, the
-  // groups' measured costs.  Consumed one after the other they were three dependent round trips of ~0.9 us each.
-  __shared__ LmHot L;
-  static_assert(sizeof(LmHot) % 4 == 0, "LmHot is copied as dwords");
-  constexpr int kHotWords = (int)(sizeof(LmHot) / 4), kHotPerThread = (kHotWords + kSolveThreads - 1) / kSolveThreads;
-  constexpr int kCostPerThread = kMaxOrderGroups / kSolveThreads;
-  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups;
-  int hv[kHotPerThread];
-#pragma unroll
-  for (int k = 0; k < kHotPerThread; ++k) {
-    const int w = threadIdx.x + k * kSolveThreads;
-    hv[k] = w < kHotWords ? reinterpret_cast<const int*>(&st->hot)[w] : 0;
-  }
-  // (One CU moves 64 B per clock: the 222 KB of 866 rows are ~3.5k cycles on top of the latency.  Rows beyond the grid are skipped by
-  // a branch each: fetching a stand-in row instead - branch-free issue - measured slower, the stand-ins pile up on one channel.)
-  const int last_row = a.nblocks - 1;
-  double2 p[kSolveChunk];
-#pragma unroll
-  for (int j = 0; j < kSolveChunk; ++j) {
-    const int gi = sb + j * kSolveSubs;
-    p[j] = gi <= last_row ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
-  }
-  int oc[kCostPerThread];
-#pragma unroll
-  for (int k = 0; k < kCostPerThread; ++k) {
-    const int gi = threadIdx.x + k * kSolveThreads;
-    oc[k] = (order_it && gi <= last_row) ? a.grp_cost[gi] : 0;
-  }
-  if (a.mode == 0 && done_at_entry) return;  // (a scalar load issued at the top: it does not wait for the vector loads above)
-  // The serial lane works on the LDS image of the state in place (a register-resident copy needs ~260 VGPRs: it spills at two
-  // waves per SIMD), and wave 0 stores it back with one coalesced pass.
-#pragma unroll
-  for (int k = 0; k < kHotPerThread; ++k) {
-    const int w = threadIdx.x + k * kSolveThreads;
-    if (w < kHotWords) reinterpret_cast<int*>(&L)[w] = hv[k];
-  }
-  if (order_it) {  // the groups' costs, for the launch order built further down (visible after the barriers below)
-#pragma unroll
-    for (int k = 0; k < kCostPerThread; ++k) {
-      const int gi = threadIdx.x + k * kSolveThreads;
-      if (gi < a.nblocks) ord_cost[gi] = oc[k];
-    }
-  }
-  {
-    double a0 = p[0].x, a1 = p[0].y;  // (not 0.0 + p[0]: the compiler places that add, and a wait for the first load alone, before the other loads)
-#pragma unroll
-    for (int j = 1; j < kSolveChunk; ++j) {
-      a0 += p[j].x;
-      a1 += p[j].y;
-    }
-    for (int g0 = sb + kSolveSubs * kSolveChunk; g0 <= last_row; g0 += kSolveSubs * kSolveChunk) {  // larger grids: further steps
-#pragma unroll
-      for (int j = 0; j < kSolveChunk; ++j) {
-        const int gi = g0 + j * kSolveSubs;
-        p[j] = gi <= last_row ? rows[(size_t)gi * (kNumSlots / 2)] : make_double2(0.0, 0.0);
-      }
-#pragma unroll
-      for (int j = 0; j < kSolveChunk; ++j) {
-        a0 += p[j].x;
-        a1 += p[j].y;
-      }
-    }
-    NG_SSTAMP(1);
-    wsum[sb][2 * vp] = a0;
-    wsum[sb][2 * vp + 1] = a1;
-  }
-  __syncthreads();
-  if (threadIdx.x < kPartialStride) {
-    const int v = threadIdx.x;
-    double t = 0.0;
-    if (v < kNumSlots)
-      for (int sb = 0; sb < kSolveSubs; ++sb) t += wsum[sb][v];
-    sums[v] = t;
-  }
-  __syncthreads();
-  NG_SSTAMP(2);
-  if (a.sums_out && threadIdx.x < kPartialStride) a.sums_out[threadIdx.x] = sums[threadIdx.x];
-  if (a.mode == 3) return;  // reduce only (point-sharded stepping: the caller all-reduces sums_out)
-  if (order_it && wave >= 1) {
-    const unsigned long long t_ord = a.dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    // ---- launch order of the next pass, built by waves 1..7 (costs already in LDS) while lane 0 of wave 0 runs the state machine:
-    //      a counting sort into 16 cost classes relative to the slowest group, heaviest class first, ascending group index inside
-    //      a class.  (The pass's results do not depend on the launch order.) ----
-    // A lone wave is bound by the latency of its own LDS round trips (~600 cycles per 64 groups and loop: 7 us for 866 groups, 17 us
-    // for 2217 - longer than the state machine), so every wave sorts a contiguous SLICE of the groups: it counts its slice per class,
-    // the seven waves meet at a counter in LDS (all waves of a block are resident: the wait cannot deadlock, and it is bounded), and
-    // each then knows where its slice starts inside every class.  No per-lane atomics and no per-class loops: four ballots (one per
-    // bit of the class) give every lane the mask of the lanes that share its class; its rank is a popcount, and the lowest lane of
-    // each class moves the class's counter in LDS (distinct addresses per class; same-wave LDS operations are ordered).
-    constexpr int kSortWaves = kSolveThreads / 64 - 1;
-    const int sw = wave - 1;
-    auto wsync = [] {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    auto same_class = [&](int cls, bool valid) -> unsigned long long {
-      unsigned long long m = __ballot(valid);
-#pragma unroll
-      for (int bit = 0; bit < 4; ++bit) {
-        const bool one = (cls >> bit) & 1;
-        const unsigned long long bb = __ballot(valid && one);
-        m &= one ? bb : ~bb;
-      }
-      return m;
-    };
-    if (lane < 16) ord_cnt[sw][lane] = 0;
-    int mx = 1;  // (every wave looks at all the costs: no exchange needed for the maximum)
-    for (int gi = lane; gi < a.nblocks; gi += 64) mx = max(mx, ord_cost[gi]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-    const float to_class = 16.0f / ((float)mx + 1.0f);  // (a heuristic: float rounding at class boundaries is immaterial)
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int slice = ((a.nblocks + kSortWaves * 64 - 1) / (kSortWaves * 64)) * 64;  // groups per wave, a multiple of 64
-    const int g_first = sw * slice, g_last = min(g_first + slice, a.nblocks);
-    wsync();
-    for (int g0 = g_first; g0 < g_last; g0 += 64) {
-      const int gi = g0 + lane;
-      const bool valid = gi < g_last;
-      const int cls = valid ? 15 - min(15, (int)((float)ord_cost[gi] * to_class)) : 0;
-      if (valid) ord_cls[gi] = (unsigned char)cls;
-      const unsigned long long m = same_class(cls, valid);
-      if (valid && (m & lt) == 0) ord_cnt[sw][cls] += __popcll(m);  // the class's lowest lane
-      wsync();
-    }
-    // the seven waves meet
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicAdd(&ord_arrived, 1);
-    bool met = false;
-    for (int spin = 0; spin < (1 << 20); ++spin) {
-      if (*reinterpret_cast<volatile int*>(&ord_arrived) >= kSortWaves) {
-        met = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (met) {  // (never false in practice; the order of the previous refresh then simply stays)
-      if (lane < 16) {  // where this wave's slice starts inside class `lane`
-        int run = 0;
-        for (int c = 0; c < lane; ++c)
-          for (int w = 0; w < kSortWaves; ++w) run += ord_cnt[w][c];
-        for (int w = 0; w < sw; ++w) run += ord_cnt[w][lane];
-        ord_pos[sw][lane] = run;
-      }
-      wsync();
-      for (int g0 = g_first; g0 < g_last; g0 += 64) {
-        const int gi = g0 + lane;
-        const bool valid = gi < g_last;
-        const int cls = valid ? ord_cls[gi] : 0;
-        const unsigned long long m = same_class(cls, valid);
-        const int base = ord_pos[sw][cls];
-        if (valid) a.grp_order[base + __popcll(m & lt)] = gi;  // within a class: ascending group index
-        wsync();
-        if (valid && (m & lt) == 0) ord_pos[sw][cls] = base + __popcll(m);
-        wsync();
-      }
-      if (sw == 0 && lane == 0) st->order_valid = 1;
-    }
-    if (a.dbg_stamps && sw == 0 && lane == 0) a.dbg_stamps[7] = __builtin_amdgcn_s_memtime() - t_ord;
-  }
-  if (wave != 0) return;
-  if (a.mode == 2) {  // compute_error hook
-    if (lane == 0) st->hot.y0 = sums[28];
-    return;
-  }
-  if (lane == 0) {
-    if (a.mode == 1) {  // linearize hook
-      adopt_new(L, sums);
-    } else {
-      const LmConfig& cfg = a.cfg;
-      const bool gn = cfg.optimizer == 0;
-      NG_SSTAMP(3);
-      const bool accepted = lm_advance(L, cfg, sums, a.trace, a.max_trace_rows);
-      NG_SSTAMP(4);
-      if (accepted) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) st->final_hessian[i] = L.H[i];
-        if (!gn) {
-          // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
-          double den = 0.0;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
-          const double rho = (L.y0 - sums[28]) / den;
-          L.x0 = L.xi;
-          const double q = 2 * rho - 1;
-          L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - q * q * q);
-          L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
-          L.iter += 1;
-          if (L.converged || L.iter >= cfg.max_iterations) {
-            L.done = 1;
-          } else {
-            // the speculative linearisation at xi (== new x0) becomes current
-            adopt_new(L, sums);
-            L.nr_iterations = L.iter;
-            L.nu = 2.0;
-            L.trial = 0;
-            make_trial(L, L.lambda);
-          }
-        }
-      }
-      NG_SSTAMP(5);
-      if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
-      if (!L.done) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) st->xi_f[r * 4 + c] = (float)L.xi.R[r * 3 + c];
-          st->xi_f[r * 4 + 3] = (float)L.xi.t[r];
-        }
-      }
-    }
-  }
-  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag);
-  // issued before the state goes back so that the PCIe write overlaps it
-  if (a.mode == 0 && a.progress_host && lane == 0)
-    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // wave 0 stores the state image back (lane 0's LDS writes are ordered before the other lanes' reads by the fence pair)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
-  NG_SSTAMP(6);
-#undef NG_SSTAMP
-}
 
 // map correspondences (sorted source slot -> sorted target position) back to ORIGINAL indices
 __global__ void __launch_bounds__(256) k_corr_to_original(const float4* __restrict__ tpt, const float4* __restrict__ qpts, const float4* __restrict__ src_sorted,

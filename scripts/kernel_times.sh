@@ -21,6 +21,8 @@ for k,v in d.items():
         w=[x for x in v if x>15]; print('   pass', round(sum(w)/len(w),2), len(w))
         n=len(w)//4
         if n: print('   pass by position in the align (last align):', [round(x,1) for x in w[-n:]])
-    if 'lm_solve' in k: w=[x for x in v if x>5.5]; print('   solve', round(sum(w)/len(w),2), len(w), 'min', min(v))
+    if 'lm_solve' in k:
+        w=[x for x in v if x>5.5]
+        if w: print('   solve', round(sum(w)/len(w),2), len(w), 'min', min(v))
 PY
 done; done
