@@ -1627,6 +1627,59 @@ int ngicp_keyframe_add_transformed(ngicp_t* h, ngicp_t* from, const float T_colm
   });
 }
 
+int ngicp_keyframe_add_transformed_filtered(ngicp_t* h, ngicp_t* from, const float T_colmajor[16], float leaf, int* id_out) {
+  if (!from) return NGICP_ERR_ARG;
+  if (!(leaf > 0.f)) return ngicp_keyframe_add_transformed(h, from, T_colmajor, id_out);  // vf_submap_use_ == false
+  return guarded(h, [&] {
+    if (!T_colmajor) throw ArgError{NGICP_ERR_ARG, "null transform"};
+    if (h->device != from->device) throw ArgError{NGICP_ERR_ARG, "keyframe_add across devices is not supported"};
+    ensure_slot_ready(from, from->src, "source");
+    // DLO's shipped configuration (cfg/params.yaml:33-35: voxelFilter.submap.use = true, res = 0.5): transformCurrentScan
+    // (odom.cc:971-974), vf_submap.filter(*current_scan_t) (odom.cc:1160-1163), setInputSource(keyframe_cloud) +
+    // calculateSourceCovariances (odom.cc:1172-1173) - the scan is already on the device as the producer's source, and nothing of
+    // this visits the host: transform into the scan's ORIGINAL point order (the order VoxelGrid adds the points of a voxel in),
+    // VoxelGrid centroids, index build, covariances with the producer's k.
+    DeviceCloud& S = *from->src.dev;
+    const size_t n = S.n;
+    from->tfinal.ensure(16 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(from->tfinal.p, T_colmajor, 16 * sizeof(float), hipMemcpyHostToDevice, from->stream));
+    from->xyzi.ensure(n * sizeof(float4));
+    hipLaunchKernelGGL(k_transform_sorted_to_original4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, from->stream, S.pts(), (int)n, from->tfinal.as<float>(),
+                       from->xyzi.as<float4>());
+    from->filt_out = nullptr;  // (the producer's filter workspace is reused: a preprocessed scan waiting there is gone)
+    from->filt_n = 0;
+    char err[256] = {0};
+    const float4* out = nullptr;
+    int m = 0;
+    if (ngk_filter_cloud(from->stream, &from->fws, from->xyzi.as<float4>(), (int)n, 0, 0.f, leaf, &out, &m, err, sizeof(err))) throw ArgError{NGICP_ERR_HIP, err};
+    if (m <= 0) throw ArgError{NGICP_ERR_ARG, "the voxel filter left no points"};
+    from->unsorted.ensure((size_t)m * sizeof(float4));
+    const int bbox_blocks = pick_blocks((size_t)m, 1024, 512);
+    from->bbox.ensure((size_t)bbox_blocks * 8 * sizeof(float));
+    hipLaunchKernelGGL(k_xyzi_to_unsorted, dim3(bbox_blocks), dim3(256), 0, from->stream, out, m, from->unsorted.as<float4>(), from->bbox.as<float>());
+    std::vector<float> bb((size_t)bbox_blocks * 8);
+    HIP_TRY(hipMemcpyAsync(bb.data(), from->bbox.p, bb.size() * sizeof(float), hipMemcpyDeviceToHost, from->stream));
+    HIP_TRY(hipStreamSynchronize(from->stream));
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int b = 0; b < bbox_blocks; ++b)
+      for (int d = 0; d < 3; ++d) {
+        mn[d] = std::min(mn[d], bb[(size_t)b * 8 + d]);
+        mx[d] = std::max(mx[d], bb[(size_t)b * 8 + 3 + d]);
+      }
+    for (int d = 0; d < 3; ++d)
+      if (!std::isfinite(mn[d]) || !std::isfinite(mx[d]) || mn[d] > mx[d]) throw ArgError{NGICP_ERR_ARG, "transform produced non-finite coordinates"};
+    Slot tmp;
+    tmp.present = true;
+    tmp.n = (size_t)m;
+    tmp.dev = index_unsorted(from, (size_t)m, mn, mx);
+    CovSet cs;
+    compute_covs(from, tmp, cs, "keyframe");
+    HIP_TRY(hipStreamSynchronize(from->stream));
+    h->keyframes.push_back({tmp.dev, cs.data});
+    if (id_out) *id_out = (int)h->keyframes.size() - 1;
+  });
+}
+
 int ngicp_keyframe_count(const ngicp_t* h, size_t* n) {
   if (!h || !n) return NGICP_ERR_ARG;
   *n = h->keyframes.size();

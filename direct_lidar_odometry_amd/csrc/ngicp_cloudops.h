@@ -57,6 +57,16 @@ __global__ void __launch_bounds__(256) k_transform_sorted_to_original(const floa
   d[0] = o.x; d[1] = o.y; d[2] = o.z;
 }
 
+// cell-sorted device cloud -> transformed {x', y', z', 0} in ORIGINAL point order: the input of the submap voxel filter (odom.cc:1160-1163)
+__global__ void __launch_bounds__(256) k_transform_sorted_to_original4(const float4* __restrict__ sorted, int n, const float* __restrict__ T_colmajor,
+                                                                        float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = sorted[i];
+  const float3 o = transform_point_f(T_colmajor, p.x, p.y, p.z);
+  out[__float_as_int(p.w)] = make_float4(o.x, o.y, o.z, 0.f);
+}
+
 // cell-sorted device cloud -> transformed staging array {x', y', z', bitcast(original index)} (element = original index) + per-block
 // bounding-box partials of the transformed points, ready for the index build: a keyframe made from a scan that is already on
 // the device never visits the host (odom.cc:971-974 followed by :1166-1174).

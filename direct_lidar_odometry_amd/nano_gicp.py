@@ -69,7 +69,7 @@ EXPORTS = [
     "ngicp_set_target_covs", "ngicp_align", "ngicp_linearize", "ngicp_compute_error", "ngicp_get_correspondences",
     "ngicp_target_knn", "ngicp_get_lm_trace", "ngicp_get_stats", "ngicp_set_profiling", "ngicp_sharded_begin",
     "ngicp_sharded_pass", "ngicp_sharded_step", "ngicp_sharded_finish",
-    "ngicp_keyframe_add", "ngicp_keyframe_add_transformed", "ngicp_keyframe_count", "ngicp_keyframe_size", "ngicp_keyframe_clear",
+    "ngicp_keyframe_add", "ngicp_keyframe_add_transformed", "ngicp_keyframe_add_transformed_filtered", "ngicp_keyframe_count", "ngicp_keyframe_size", "ngicp_keyframe_clear",
     "ngicp_submap_set", "ngicp_get_target_points", "ngicp_transform_source", "ngicp_transform_cloud", "ngicp_measure_copy_bandwidth",
     "ngicp_preprocess_scan", "ngicp_set_source_preprocessed", "ngicp_map_add", "ngicp_map_voxel_filter", "ngicp_map_size", "ngicp_map_get",
     "ngicp_map_clear", "ngicp_math_selftest",
@@ -125,6 +125,7 @@ def load_library() -> C.CDLL:
     L.ngicp_sharded_finish.argtypes = [vp, c_f32p, c_i32p, c_i32p, c_f64p]
     L.ngicp_keyframe_add.argtypes = [vp, vp, c_i32p]
     L.ngicp_keyframe_add_transformed.argtypes = [vp, vp, c_f32p, c_i32p]
+    L.ngicp_keyframe_add_transformed_filtered.argtypes = [vp, vp, c_f32p, C.c_float, c_i32p]
     L.ngicp_keyframe_count.argtypes = [vp, C.POINTER(C.c_size_t)]
     L.ngicp_keyframe_size.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
     L.ngicp_keyframe_clear.argtypes = [vp]
@@ -384,6 +385,12 @@ class NanoGICP:
         kid = C.c_int(-1)
         t = _colmajor16(T, np.float32)
         self._ck(self._L.ngicp_keyframe_add_transformed(self._h, producer._h, _p(t, c_f32p), C.byref(kid)))
+        return kid.value
+
+    def addKeyframeTransformedFiltered(self, producer: "NanoGICP", T, leaf: float) -> int:
+        """DLO's shipped configuration (voxelFilter.submap.use, cfg/params.yaml:33-35): odom.cc:971-974 + 1160-1174 on the device."""
+        t = _colmajor16(T, np.float32); kid = C.c_int(-1)
+        self._ck(self._L.ngicp_keyframe_add_transformed_filtered(self._h, producer._h, _p(t, c_f32p), float(leaf), C.byref(kid)))
         return kid.value
 
     def numKeyframes(self) -> int: return self._covs_size("ngicp_keyframe_count")

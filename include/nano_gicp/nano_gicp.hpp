@@ -285,6 +285,12 @@ class NanoGICP {
     check(ngicp_keyframe_add_transformed(h_, producer.h_, T.data(), &id), "addKeyframeTransformed");
     return id;
   }
+  // the same with the submap voxel filter in between (DLO's shipped configuration: vf_submap_use_, odom.cc:1160-1163)
+  int addKeyframeTransformedFiltered(NanoGICP& producer, const Matrix4& T, float leaf) {
+    int id = -1;
+    check(ngicp_keyframe_add_transformed_filtered(h_, producer.h_, T.data(), leaf, &id), "addKeyframeTransformedFiltered");
+    return id;
+  }
   size_t numKeyframes() const { size_t n = 0; ngicp_keyframe_count(h_, &n); return n; }
   // target := concatenation of the given keyframes (cloud + covariances), assembled and indexed on the device; a call with
   // the id list of the current submap is a no-op.  Returns true when the target was rebuilt.

@@ -209,6 +209,11 @@ int ngicp_sharded_finish(ngicp_t* h, float T_out_colmajor[16], int* converged, i
  * Keyframe ids are dense, in insertion order (the index DLO uses for `keyframes[k]`). */
 int ngicp_keyframe_add(ngicp_t* h, ngicp_t* from, int* id_out);
 int ngicp_keyframe_add_transformed(ngicp_t* h, ngicp_t* from, const float T_colmajor[16], int* id_out);
+/* The same for DLO's SHIPPED configuration (cfg/params.yaml:33-35: voxelFilter.submap.use = true, res = 0.5), where the transformed
+ * scan is voxel-filtered BEFORE it becomes a keyframe (src/dlo/odom.cc:1160-1163): replaces odom.cc:971-974 + 1160-1174.  The
+ * keyframe is pcl::VoxelGrid(leaf) of `from`'s current source cloud transformed by T - transform (in the scan's original point
+ * order), centroids, index build and covariances all on the device.  leaf <= 0 is ngicp_keyframe_add_transformed. */
+int ngicp_keyframe_add_transformed_filtered(ngicp_t* h, ngicp_t* from, const float T_colmajor[16], float leaf, int* id_out);
 int ngicp_keyframe_count(const ngicp_t* h, size_t* n);
 int ngicp_keyframe_size(const ngicp_t* h, int id, size_t* n_points);
 int ngicp_keyframe_clear(ngicp_t* h);

@@ -240,3 +240,68 @@ def test_map_filter_between_preprocess_and_set_source_is_refused(ng):
     # and the ordinary order still works afterwards
     filtered = g.preprocessScan(cloud, True, 1.0, 0.25, intensity_col=4, set_as_source=True)
     assert len(filtered) > 100
+
+
+def test_filtered_keyframe_on_device_equals_host_route(ng, oracle_mod):
+    """DLO's shipped configuration (cfg/params.yaml:33-35: voxelFilter.submap.use = true, res = 0.5): the transformed scan is
+    voxel-filtered BEFORE it becomes a keyframe (odom.cc:1160-1163), then indexed and given covariances (odom.cc:1172-1174).
+    Device route: addKeyframeTransformedFiltered (nothing visits the host).  Host route, as the reference spells it:
+    transformPointCloud -> VoxelGrid -> setInputSource -> calculateSourceCovariances -> getSourceCovariances.  Points and
+    covariances must agree bit for bit, and with the oracle's restatements."""
+    w = clouds.scan_to_scan(30_000)
+    T = clouds.make_pose((0.4, -0.2, 0.05), (0.5, -0.3, 3.0)).astype(np.float32)
+    leaf, k = 0.5, 10
+    s2s, s2m = ng.NanoGICP(), ng.NanoGICP()
+    s2s.setCorrespondenceRandomness(k)
+    s2s.setInputSource(w.source)
+    kid = s2m.addKeyframeTransformedFiltered(s2s, T, leaf)
+    assert kid == 0 and 100 < s2m.keyframeSize(kid) < len(w.source)
+    s2m.setSubmapKeyframes([kid])
+    dev_pts, dev_covs = s2m.targetPoints(), s2m.getTargetCovariances()
+    # host route through the same engine pieces
+    scan_t = s2s.transformSource(T)                                              # odom.cc:971-974
+    filt = ng.NanoGICP().preprocessScan(np.c_[scan_t, np.zeros(len(scan_t), np.float32)], remove_nan=False, crop_size=0.0, voxel_res=leaf, intensity_col=3)
+    host = ng.NanoGICP(); host.setCorrespondenceRandomness(k)
+    host.setInputSource(np.ascontiguousarray(filt[:, :3])); host.calculateSourceCovariances()
+    assert np.array_equal(dev_pts, filt[:, :3])
+    assert np.array_equal(dev_covs, host.getSourceCovariances())
+    # and against the oracle's restatements of transformPointCloud / VoxelGrid / calculate_covariances
+    ref_t = oracle_mod.transform_cloud(w.source, T)
+    ref_f = oracle_mod.filter_cloud(np.c_[ref_t, np.zeros(len(ref_t), np.float32)], False, 0.0, leaf, intensity_col=3)
+    assert np.array_equal(dev_pts, ref_f[:, :3])
+    ref_c = oracle_mod.covariances(np.ascontiguousarray(ref_f[:, :3]), k, 3, 16)
+    _, d2 = oracle_mod.OracleTree(np.ascontiguousarray(ref_f[:, :3])).knn(np.ascontiguousarray(ref_f[:, :3]), k + 1, 16)
+    ties = d2[:, k - 1] == d2[:, k]
+    assert np.abs(dev_covs - ref_c)[~ties].max() < 1e-9
+    # leaf <= 0 falls back to the unfiltered device route
+    kid2 = s2m.addKeyframeTransformedFiltered(s2s, T, 0.0)
+    assert s2m.keyframeSize(kid2) == len(w.source)
+    # the producer's own source slot is untouched
+    s2s.setInputTarget(w.target); s2s.setMaxCorrespondenceDistance(1.0); s2s.align()
+    ref = ng.NanoGICP(); ref.setCorrespondenceRandomness(k); ref.setMaxCorrespondenceDistance(1.0); ref.setInputSource(w.source); ref.setInputTarget(w.target); ref.align()
+    assert np.array_equal(s2s.getFinalTransformation(), ref.getFinalTransformation())
+
+
+def test_map_voxel_filter_one_million_points(ng, oracle_mod):
+    """dlo::MapNode at map scale (map.cc:100-131): ten 100k-point keyframes accumulated, the 1M-point map voxel-filtered twice (two
+    publish ticks) - the engine's own stable radix sort over 20-odd key bits, against the oracle's restatement, bit for bit."""
+    w = clouds.scan_to_submap(100_000, 10)
+    assert len(w.target) == 1_000_000
+    rng = np.random.default_rng(11)
+    cloud = np.c_[w.target, rng.uniform(0, 255, len(w.target)).astype(np.float32)]
+    g = ng.NanoGICP()
+    lo = 0
+    for n in w.keyframe_sizes:
+        g.mapAdd(np.ascontiguousarray(cloud[lo:lo + n]), intensity_col=3)
+        lo += n
+    assert g.mapSize() == 1_000_000
+    host = cloud
+    for leaf in (0.3, 0.5):
+        m = g.mapVoxelFilter(leaf)
+        host = oracle_mod.filter_cloud(host, False, 0.0, leaf, intensity_col=3)
+        assert m == len(host) and 1000 < m < 1_000_000
+        assert np.array_equal(g.mapGet(), host)
+    # a leaf so small that the voxel indices would overflow an int: PCL warns and leaves the cloud as it is
+    before = g.mapGet()
+    assert g.mapVoxelFilter(1e-6) == len(before)
+    assert np.array_equal(g.mapGet(), before)
