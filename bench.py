@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """bench.py — GICP iterations/s + ms/scan of the NanoGICP align() hot path on MI355X.
 
+`--mode sharded` (any N; also run as the extra key `sharded_c5` at N > 1): ONE 250k -> 2M alignment whose source points are split
+over the ranks, one 256-byte RCCL all-reduce per pass (SURVEY.md §8e way 2), covariances sharded with an all-gather.
+
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): scan-to-submap,
 100k-point VLP-16-shaped source vs a 500k-point submap (5 keyframes x 100k, per-keyframe world-frame
 covariances supplied as DLO does), k = 20, max-corr 0.5 m, exactly 20 GICP iterations per align()
@@ -79,8 +82,9 @@ def dlo_frame_ms(ng, w, tgt_covs, device, frames=4):
             out.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s2s.stats()["passes"], s2m.stats()["passes"], s2s.stats()["loop_ms"],
                         s2m.stats()["loop_ms"], s2m.stats()["align_ms"], build_ms, s2s.stats()["covariance_ms"]))
     a = np.array(out)
+    err_gt = clouds.pose_error(s2m.getFinalTransformation(), w.gt)  # (the last scan is the workload's scan shifted by a few millimetres)
     s2s.close(); s2m.close()
-    return {"frame_ms": float(a[:, :3].sum(1).mean()), "source_upload_index_covariances_ms": float(a[:, 0].mean()),
+    return {"frame_ms": float(a[:, :3].sum(1).mean()), "scan_to_submap_error_vs_ground_truth_m_rad": [float(err_gt[0]), float(err_gt[1])], "source_upload_index_covariances_ms": float(a[:, 0].mean()),
             "scan_to_scan_align_ms": float(a[:, 1].mean()), "scan_to_submap_align_ms": float(a[:, 2].mean()),
             "scan_to_scan_passes": float(a[:, 3].mean()), "scan_to_submap_passes": float(a[:, 4].mean()),
             "scan_to_scan_device_loop_ms": float(a[:, 5].mean()), "scan_to_submap_device_loop_ms": float(a[:, 6].mean()),
@@ -89,24 +93,32 @@ def dlo_frame_ms(ng, w, tgt_covs, device, frames=4):
             "settings": "DLO cfg/params.yaml: s2s k=10 gate 1.0 m, s2m k=20 gate 0.5 m, 32 iterations max, eps 0.01; 100k-point scans, 500k-point submap"}
 
 
-def ms_per_scan_gpu(g, w, reps=6):
+def ms_per_scan_gpu(g, w, reps=50):
     """SURVEY.md §8d `ms/scan`: wall time of one complete align() of a scan the engine has not seen: upload + index build of the
     source, its lazily computed covariances (impl/nano_gicp_impl.hpp:163-168), all 20 iterations, the output transform (K5) and
     the download of the aligned cloud.  The 500k-point submap (index + covariances) is resident: DLO changes it only when the
-    keyframe set changes (odom.cc:827).  Median of `reps` after one warm-up."""
-    scans = [np.ascontiguousarray(w.source + np.float32(1e-4 * (i + 1))) for i in range(reps + 1)]
-    t = []
-    for i, scan in enumerate(scans):
+    keyframe set changes (odom.cc:827).  `reps` scans after one warm-up: median, p99 and maximum, and for the slowest scan what the
+    engine's own timers say (a device allocation in the middle of a frame, the upload, the index build or the loop)."""
+    base = [np.ascontiguousarray(w.source + np.float32(1e-4 * (i + 1))) for i in range(8)]  # distinct buffers, like new scans
+    t, detail = [], []
+    for i in range(reps + 1):
+        scan = base[i % len(base)]
+        a0 = g.stats()["device_allocs"]
         t0 = time.perf_counter()
-        g.setInputSource(scan)
+        g.setInputSource(scan, identity=1000 + i)  # a new cloud object every frame (pointer identity, impl/nano_gicp_impl.hpp:122)
+        t1 = time.perf_counter()
         out = g.align(w.guess, want_aligned=True)
         dt = (time.perf_counter() - t0) * 1e3
         assert out.shape == (len(scan), 3)
         if i:
+            s = g.stats()
             t.append(dt)
+            detail.append({"ms": dt, "set_source_ms": (t1 - t0) * 1e3, "upload_ms": s["upload_ms"], "index_build_ms": s["index_build_ms"], "align_call_ms": s["align_ms"],
+                           "device_loop_ms": s["loop_ms"], "device_allocs_during": int(s["device_allocs"] - a0), "host_wait_spins": int(s["host_wait_spins"])})
     g.setInputSource(w.source)
     g.calculateSourceCovariances()
-    return {"median_ms": statistics.median(t), "min_ms": min(t), "max_ms": max(t), "reps": len(t),
+    worst = max(detail, key=lambda d: d["ms"])
+    return {"median_ms": statistics.median(t), "p99_ms": float(np.percentile(t, 99)), "min_ms": min(t), "max_ms": max(t), "reps": len(t), "slowest_scan": worst,
             "includes": "host->device upload of the 100k scan (12 B/pt, pageable), index build, source covariances (k=20), 20 iterations "
                         "(21 fused passes), output transform, device->host download of the aligned cloud; submap resident"}
 
@@ -115,6 +127,7 @@ def submap_routes_ms(ng, w, device, reps=3):
     """handing a changed submap (5 keyframes x 100k) to the s2m engine — the reference's host route
     (setInputTarget(host concat) + setTargetCovariances(N x Matrix4d), odom.cc:830-833) against the device-resident keyframe
     store (ngicp_submap_set).  Keyframe covariances exist beforehand in both routes."""
+    from direct_lidar_odometry_amd import clouds
     s2s, s2m = ng.NanoGICP(device=device), ng.NanoGICP(device=device)
     s2s.setCorrespondenceRandomness(10)
     kfs = np.split(w.target, np.cumsum(w.keyframe_sizes)[:-1])
@@ -139,10 +152,31 @@ def submap_routes_ms(ng, w, device, reps=3):
         assert changed
         if r:
             t_host.append((t1 - t0) * 1e3); t_dev.append((t3 - t2) * 1e3)
+    # DLO's shipped configuration voxel-filters the transformed scan before it becomes a keyframe (odom.cc:1160-1174, cfg/params.yaml:33-35)
+    T = clouds.gt_transform().astype(np.float32)
+    s2s.setInputSource(w.source)
+    t_kf_host, t_kf_dev = [], []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        scan_t = s2s.transformSource(T)                                                               # odom.cc:971-974 (device transform, host result)
+        filt = s2m.preprocessScan(np.c_[scan_t, np.zeros(len(scan_t), np.float32)], False, 0.0, 0.5, intensity_col=3)  # vf_submap.filter
+        kfe = ng.NanoGICP(device=device); kfe.setCorrespondenceRandomness(10)
+        kfe.setInputSource(np.ascontiguousarray(filt[:, :3])); kfe.calculateSourceCovariances(); normals_kf = kfe.getSourceCovariances()  # odom.cc:1172-1174
+        t1 = time.perf_counter()
+        kfe.close()
+        kid = s2m.addKeyframeTransformedFiltered(s2s, T, 0.5); s2m.stats()
+        t2 = time.perf_counter()
+        if r:
+            t_kf_host.append((t1 - t0) * 1e3); t_kf_dev.append((t2 - t1) * 1e3)
+    kf_points = s2m.keyframeSize(kid)
     s2s.close(); s2m.close()
     return {"host_route_ms": statistics.median(t_host), "device_route_ms": statistics.median(t_dev), "keyframes": len(kfs), "points": int(len(w.target)),
             "host_route": "setInputTarget(500k x 12 B) + setTargetCovariances(500k x 128 B) (odom.cc:830-833)",
-            "device_route": "ngicp_submap_set: device concat of the keyframes' points + covariances, one index build, no host traffic"}
+            "device_route": "ngicp_submap_set: device concat of the keyframes' points + covariances, one index build, no host traffic",
+            "new_keyframe_filtered": {"host_route_ms": statistics.median(t_kf_host), "device_route_ms": statistics.median(t_kf_dev), "points_in": int(len(w.source)),
+                                      "points_out": int(kf_points), "leaf_m": 0.5,
+                                      "host_route": "transformPointCloud + VoxelGrid(0.5) + setInputSource + calculateSourceCovariances + getSourceCovariances (odom.cc:971-974,1160-1174)",
+                                      "device_route": "ngicp_keyframe_add_transformed_filtered"}}
 
 
 def preprocess_ms(ng, w, device, reps=4):
@@ -235,6 +269,15 @@ def cpu_baseline(w, tgt_covs, src_covs):
             "target_index_build_ms": build_s * 1e3}, T_cpu, it_cpu, conv_cpu
 
 
+def roofline_extras(block: dict, bytes_per_launch, avg_pass_ms, copy_gbps):
+    """Figures that move the right way when the search gets leaner (the byte count behind `frac` is proportional to the candidates
+    per query): time per pass, and the achieved rate against the copy rate MEASURED on this box."""
+    block["time_per_pass_us"] = avg_pass_ms * 1e3
+    if isinstance(copy_gbps, (int, float)) and copy_gbps > 0 and avg_pass_ms > 0:
+        block["frac_of_measured_copy"] = bytes_per_launch / (avg_pass_ms * 1e-3) / 1e9 / copy_gbps
+    return block
+
+
 def roofline_block(n_src, cbar, passes_per_align, avg_pass_ms):
     # SURVEY.md §8d: bytes per iteration = N_s * (12*Cbar + 100 + 52*n_trials); the fused pass carries one trial's K4 reads
     # except in the first pass of an align (no previous linearisation yet)
@@ -247,7 +290,7 @@ def roofline_block(n_src, cbar, passes_per_align, avg_pass_ms):
 
 def committed_traffic(cfg):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (separate runs; NOT measured in this run)."""
-    for fn in (f"r02_{cfg}_pass_counters.json", "r01_pass_hbm_traffic.json" if cfg == "c3" else ""):
+    for fn in (f"r03_{cfg}_pass_counters.json", f"r02_{cfg}_pass_counters.json", "r01_pass_hbm_traffic.json" if cfg == "c3" else ""):
         if not fn:
             continue
         p = os.path.join(ROOT, "profiles", fn)
@@ -259,7 +302,7 @@ def committed_traffic(cfg):
     return None, None
 
 
-def c5_leg(ng, device, aligns=5, warmup=2):
+def c5_leg(ng, device, aligns=5, warmup=2, copy_gbps=None):
     """BASELINE configs[4]: 250k-point OS1-128-shaped scan vs a 2M-point submap of 8 keyframes (device-resident keyframe store)."""
     from direct_lidar_odometry_amd import clouds
     w = clouds.scan_to_submap(250_000, 8, shape="os1")
@@ -296,8 +339,102 @@ def c5_leg(ng, device, aligns=5, warmup=2):
            "algorithmic_bytes_per_launch": nbytes, "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS, "floor_frac_cbar1": floor,
            "traffic_bytes_per_launch": traffic, "traffic_source": src, "voxel_m": s["voxel_size"], "grid": s["grid_dims"],
            "submap_device_assembly_ms": submap_ms, "final_error_vs_ground_truth": list(clouds.pose_error(g.getFinalTransformation(), w.gt))}
+    roofline_extras(out, nbytes, avg, copy_gbps)
     s2s.close(); g.close()
     return out
+
+
+def sharded_c5_leg(ng, dist, world, rank, device, steps=5, warmup=2):
+    """SURVEY.md §8e way 2 on BASELINE configs[4]: ONE 250k -> 2M alignment whose source points are split over the ranks.  The target
+    (8 keyframes, device keyframe store) is replicated on every rank; K1 of every keyframe and of the scan is itself sharded (each
+    rank computes a block of the packed covariance array, the blocks are all-gathered).  Per pass: the fused kernel over this rank's
+    block, ONE all-reduce of 32 doubles (what is reduced is the reference's own partial sum, impl/nano_gicp_impl.hpp:260-267), the
+    identical LM step on every rank.  Strong scaling: the total work is fixed."""
+    import torch
+    from direct_lidar_odometry_amd import clouds, sharding
+    dev = f"cuda:{device}"
+    w = clouds.scan_to_submap(250_000, 8, shape="os1")
+    prod, g = ng.NanoGICP(device=device), ng.NanoGICP(device=device)
+    prod.setCorrespondenceRandomness(20)
+    g.setCorrespondenceRandomness(20); g.setMaxCorrespondenceDistance(w.max_corr_dist)
+    g.setMaximumIterations(GICP_ITERS); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
+    t0 = time.perf_counter()
+    lo = 0
+    for n in w.keyframe_sizes:  # keyframe covariances: K1 sharded, blocks all-gathered, then the keyframe goes to the store
+        prod.setInputSource(np.ascontiguousarray(w.target[lo:lo + n]))
+        sharding.sharded_covariances(prod, 0, dist, dev)
+        g.addKeyframe(prod)
+        lo += n
+    g.setSubmapKeyframes(list(range(len(w.keyframe_sizes))))
+    prod.setInputSource(w.source)
+    sharding.sharded_covariances(prod, 0, dist, dev)
+    src_covs = prod.getSourceCovariances()
+    a, b = sharding.shard_bounds(len(w.source), world, rank)
+    g.setInputSource(np.ascontiguousarray(w.source[a:b])); g.setSourceCovariances(src_covs[a:b])
+    torch.cuda.synchronize(); dist.barrier()
+    setup_s = time.perf_counter() - t0
+    for _ in range(warmup):
+        T = sharding.sharded_align(g, w.guess, dist, dev)
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(steps):
+        T = sharding.sharded_align(g, w.guess, dist, dev)
+        iters += g.nr_iterations_ + 1
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    # what the collective costs: the same 256-byte all-reduce in a loop of its own
+    buf = torch.zeros(32, dtype=torch.float64, device=dev)
+    for _ in range(20):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(200):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    ar_us = (time.perf_counter() - t1) / 200 * 1e6
+    # every rank must hold the identical pose (no broadcast is ever made)
+    Tt = torch.tensor(np.asarray(T, np.float64), device=dev); Ts = [torch.zeros_like(Tt) for _ in range(world)]
+    dist.all_gather(Ts, Tt)
+    same = all(bool(torch.equal(Ts[0], x)) for x in Ts)
+    passes_per_align = iters / steps + 1 + 2  # one pass per iteration + the first linearisation + the constant reporting lag (no-op passes)
+    out = {"workload": "scan_to_submap_250k_vs_2M_os1 (BASELINE configs[4]), source points split over the ranks", "rccl_ranks": world, "backend": dist.get_backend(),
+           "source_points_per_rank": int(b - a), "ms_per_align": elapsed * 1e3 / steps, "iterations_per_s": iters / elapsed, "iterations_per_align": iters / steps,
+           "us_per_iteration": elapsed * 1e6 / max(1, iters), "allreduce_256B_us": ar_us,
+           "allreduce_share_of_align": ar_us * passes_per_align / (elapsed * 1e6 / steps), "poses_identical_on_all_ranks": same,
+           "final_error_vs_ground_truth": list(clouds.pose_error(T, w.gt)), "setup_s_incl_sharded_covariances": setup_s, "scaling": "strong"}
+    prod.close(); g.close()
+    return out
+
+
+def main_sharded(args):
+    """--mode sharded: only the point-sharded c5 alignment (SURVEY.md §8e way 2), at any rank count (N = 1: a single-rank RCCL group)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ and "RANK" in os.environ:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    from direct_lidar_odometry_amd import build, nano_gicp as ng
+    if rank == 0:
+        build.build()
+    dist.barrier()
+    leg = sharded_c5_leg(ng, dist, world, rank, local_rank, steps=args.steps if args.steps else 5, warmup=max(1, args.warmup))
+    if rank == 0:
+        out = {"metric": "gicp_iterations_per_sec", "value": leg["iterations_per_s"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": leg["ms_per_align"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": leg["workload"], "source_points": 250000, "target_points": 2000000, "k_correspondences": 20, "gicp_iterations_per_align": GICP_ITERS,
+                          "optimizer": "LevenbergMarquardt", "parallelism": f"point_sharded_x{world}"},
+               "sharded": leg}
+        print(json.dumps(out), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -307,7 +444,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c5 / dlo_frame / submap / ms_per_scan extras (profiling runs)")
+    ap.add_argument("--mode", choices=["independent", "sharded"], default="independent",
+                    help="independent (default, BASELINE configs[2]/[3]): one 100k -> 500k alignment per rank; sharded: ONE 250k -> 2M alignment split over the ranks")
     args = ap.parse_args()
+    if args.mode == "sharded":
+        return main_sharded(args)
 
     import torch
     import torch.distributed as dist
@@ -379,6 +520,12 @@ def main():
     T_gpu = g.getFinalTransformation().copy()
     it_gpu, conv_gpu = g.nr_iterations_, g.converged_
 
+    sharded_extra = None
+    if world > 1 and not args.no_extras:  # every rank takes part; rank 0 reports (the headline above is already measured)
+        try:
+            sharded_extra = sharded_c5_leg(ng, dist, world, rank, local_rank, steps=3, warmup=1)
+        except Exception as exc:
+            sharded_extra = {"error": f"{type(exc).__name__}: {exc}"}
     parity_ok = True
     if rank == 0:
         s = g.stats()
@@ -420,18 +567,22 @@ def main():
             try:
                 out["hbm_copy_measured_GBps"] = g.measureCopyBandwidth(1 << 30, 10)
                 out["roofline"]["hbm_copy_measured_GBps"] = out["hbm_copy_measured_GBps"]
+                roofline_extras(out["roofline"], bytes_per_launch, avg_pass_ms, out["hbm_copy_measured_GBps"])
             except Exception as exc:
                 out["hbm_copy_measured_GBps"] = {"error": str(exc)}
         if world == 1 and not args.no_extras:
+            copy_rate = out.get("hbm_copy_measured_GBps")
             for key, fn in (("ms_per_scan_detail", lambda: ms_per_scan_gpu(g, w)), ("dlo_frame", lambda: dlo_frame_ms(ng, w, tgt_covs, local_rank)),
                             ("submap", lambda: submap_routes_ms(ng, w, local_rank)), ("preprocess", lambda: preprocess_ms(ng, w, local_rank)),
-                            ("c5", lambda: c5_leg(ng, local_rank))):
+                            ("c5", lambda: c5_leg(ng, local_rank, copy_gbps=copy_rate))):
                 try:
                     out[key] = fn()
                 except Exception as exc:  # informative extras, never fatal
                     out[key] = {"error": f"{type(exc).__name__}: {exc}"}
             if isinstance(out.get("ms_per_scan_detail"), dict) and "median_ms" in out["ms_per_scan_detail"]:
                 out["ms_per_scan"] = out["ms_per_scan_detail"]["median_ms"]
+        if sharded_extra is not None:
+            out["sharded_c5"] = sharded_extra
         if world == 1 and not args.no_cpu_baseline:
             base, T_cpu, it_cpu, conv_cpu = cpu_baseline(w, tgt_covs, src_covs)
             out["cpu_baseline"] = base

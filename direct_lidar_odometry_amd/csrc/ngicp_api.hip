@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <sched.h>
 #include <string>
 #include <vector>
 
@@ -51,6 +53,8 @@ double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+std::atomic<long long> g_device_allocs{0};  // hipMalloc calls of the engine's buffers (ngicp_stats::device_allocs)
+
 // grow-only device buffer
 struct DevBuf {
   void* p = nullptr;
@@ -68,6 +72,7 @@ struct DevBuf {
     cap = 0;
     size_t want = bytes + bytes / 4 + 256;
     HIP_TRY(hipMalloc(&p, want));
+    g_device_allocs.fetch_add(1, std::memory_order_relaxed);
     cap = want;
   }
   bool ensure_grew(size_t bytes) {  // true when the buffer was (re)allocated: its contents are gone
@@ -259,9 +264,14 @@ struct ngicp {
   Params p;
   double voxel_size = 0.0;  // 0 = auto
   double target_occupancy = 24.0;  // mean points a random point sees in its own cell; tuned on MI355X (c2/c3/c5 workloads)
+  int host_wait = 0;        // 0: poll without giving the core up, 1: sched_yield between polls (ngicp_set_host_wait)
+  CovSet shard_covs[2];     // covariance sets being computed in blocks by several ranks (ngicp_covs_shard_*), uncommitted
   int chunk_pairs = 3;      // (pass, solve) pairs kept in flight ahead of the solver's published progress (env NGICP_CHUNK)
   int stage_grow = 6;       // upper limit of rings served from the LDS stage
-  std::pair<size_t, double> voxel_memo[2] = {{0, 0.0}, {0, 0.0}};  // {cloud size, auto voxel edge} of recent builds
+  // {cloud size, auto voxel edge} of recent builds, one entry per size class (a factor of two around the size): a DLO pipeline has three
+  // or four - the scan, the voxel-filtered keyframe made from it, the submap - and each would otherwise pay the refinement passes again
+  std::pair<size_t, double> voxel_memo[4] = {{0, 0.0}, {0, 0.0}, {0, 0.0}, {0, 0.0}};
+  int voxel_memo_next = 0;
   bool profiling = false;
   int prof_stride = 1;      // time every prof_stride-th pass launch (events between kernels cost a few microseconds each)
 
@@ -524,8 +534,16 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
       const double lam = (double)occ / (double)n, ratio = h->target_occupancy / std::max(lam, 1.0);
       if (!(ratio > 0.75 && ratio < 1.33)) next_h = std::max(0.01, next_h * std::min(4.0, std::max(0.25, std::pow(ratio, 1.0 / 1.5))));
     }
-    int slot = 0;
-    if (h->voxel_memo[0].second > 0.0 && !((double)n > 0.5 * (double)h->voxel_memo[0].first && (double)n < 2.0 * (double)h->voxel_memo[0].first)) slot = 1;
+    int slot = -1;
+    for (int i = 0; i < 4; ++i)  // the entry of this size class, else an empty one, else the oldest
+      if (h->voxel_memo[i].second > 0.0 && (double)n > 0.5 * (double)h->voxel_memo[i].first && (double)n < 2.0 * (double)h->voxel_memo[i].first) slot = i;
+    if (slot < 0)
+      for (int i = 0; i < 4 && slot < 0; ++i)
+        if (!(h->voxel_memo[i].second > 0.0)) slot = i;
+    if (slot < 0) {
+      slot = h->voxel_memo_next;
+      h->voxel_memo_next = (h->voxel_memo_next + 1) % 4;
+    }
     h->voxel_memo[slot] = {n, next_h};
   }
   float ms = 0.f;
@@ -560,14 +578,28 @@ void ensure_slot_ready(ngicp* h, Slot& s, const char* what) {
 // Covariances
 // ------------------------------------------------------------------------------------------
 template <int K>
-void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out) {
-  const dim3 grid((unsigned)((dc.n + kKnnPairs - 1) / kKnnPairs)), block(kKnnBlock);
+void launch_cov(ngicp* h, DeviceCloud& dc, int k, int reg, double* out, size_t lo, size_t hi, hipStream_t s) {
+  if (hi <= lo) return;
+  const dim3 grid((unsigned)((hi - lo + kKnnPairs - 1) / kKnnPairs)), block(kKnnBlock);
   // window size by cloud size (see knn_take_window): a scan that does not fill the chip is as slow as one wave's chain of round
   // trips - wider windows; a large cloud is bound by what its waves fetch and insert - narrow ones
   if (dc.n < 160000)
-    hipLaunchKernelGGL((k_covariances<K, 6>), grid, block, 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k, reg, out);
+    hipLaunchKernelGGL((k_covariances<K, 6>), grid, block, 0, s, dc.pts(), dc.cells(), dc.grid, (int)lo, (int)hi, k, reg, out);
   else
-    hipLaunchKernelGGL((k_covariances<K, 4>), grid, block, 0, h->stream, dc.pts(), dc.cells(), dc.grid, (int)dc.n, k, reg, out);
+    hipLaunchKernelGGL((k_covariances<K, 4>), grid, block, 0, s, dc.pts(), dc.cells(), dc.grid, (int)lo, (int)hi, k, reg, out);
+}
+
+// covariances of the points at sorted positions [lo, hi) into `out` ([n][6], sorted order)
+void launch_cov_range(ngicp* h, DeviceCloud& dc, double* out, size_t lo, size_t hi, hipStream_t s) {
+  const int k = h->p.k, reg = h->p.regularization;
+  if (k <= 0) throw ArgError{NGICP_ERR_ARG, "k must be positive"};
+  if (k > 32 || (size_t)k > dc.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
+  if (k <= 10)
+    launch_cov<10>(h, dc, k, reg, out, lo, hi, s);
+  else if (k <= 20)
+    launch_cov<20>(h, dc, k, reg, out, lo, hi, s);
+  else
+    launch_cov<32>(h, dc, k, reg, out, lo, hi, s);
 }
 
 void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
@@ -578,13 +610,7 @@ void compute_covs(ngicp* h, Slot& slot, CovSet& cs, const char* what) {
   if (k > 32 || (size_t)k > dc.n) throw ArgError{NGICP_ERR_K_TOO_LARGE, "k exceeds the cloud size or the engine limit of 32"};
   auto buf = acquire_buf(h, h->device, dc.n * 6 * sizeof(double));
   HIP_TRY(hipEventRecord(h->ev_cov_a, h->stream));
-  const int reg = h->p.regularization;
-  if (k <= 10)
-    launch_cov<10>(h, dc, k, reg, buf->as<double>());
-  else if (k <= 20)
-    launch_cov<20>(h, dc, k, reg, buf->as<double>());
-  else
-    launch_cov<32>(h, dc, k, reg, buf->as<double>());
+  launch_cov_range(h, dc, buf->as<double>(), 0, dc.n, h->stream);
   HIP_TRY(hipEventRecord(h->ev_cov_b, h->stream));
   HIP_TRY(hipGetLastError());
   h->cov_timing_pending = true;  // no synchronisation here: the covariances are consumed on this same stream
@@ -914,8 +940,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     const int prog = *reinterpret_cast<volatile int*>(h->h_progress);
     if (prog & kProgressDone) break;
     if (launched - (long)(prog & kProgressMask) >= depth) {  // enough in flight: wait for the device to catch up
-      if ((++spins & 0xfffff) == 0 && now_ms() - t_loop > 30000.0) throw ArgError{NGICP_ERR_HIP, "the registration loop did not finish within 30 s"};
-      __builtin_ia32_pause();
+      if ((++spins & (h->host_wait ? 0xfff : 0xfffff)) == 0 && now_ms() - t_loop > 30000.0) throw ArgError{NGICP_ERR_HIP, "the registration loop did not finish within 30 s"};
+      if (h->host_wait) sched_yield(); else __builtin_ia32_pause();
       continue;
     }
     const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
@@ -1015,6 +1041,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   }
   s.n_src = (long long)h->src.dev->n;
   s.n_tgt = (long long)h->tgt.dev->n;
+  s.host_wait_spins = (long long)spins;
   s.align_ms = now_ms() - t_begin;
 }
 
@@ -1462,7 +1489,13 @@ int ngicp_get_stats(ngicp_t* h, ngicp_stats* out) {
     if (hipEventSynchronize(h->ev_cov_b) == hipSuccess && hipEventElapsedTime(&ms, h->ev_cov_a, h->ev_cov_b) == hipSuccess) h->stats.covariance_ms = ms;
     h->cov_timing_pending = false;
   }
+  h->stats.device_allocs = g_device_allocs.load(std::memory_order_relaxed);
   *out = h->stats;
+  return NGICP_OK;
+}
+int ngicp_set_host_wait(ngicp_t* h, int mode) {
+  if (!h || (mode != 0 && mode != 1)) return NGICP_ERR_ARG;
+  h->host_wait = mode;
   return NGICP_OK;
 }
 int ngicp_set_profiling(ngicp_t* h, int on) {
@@ -1568,6 +1601,43 @@ int ngicp_sharded_finish(ngicp_t* h, float T_out[16], int* converged, int* nr_it
     h->sharded_active = false;
     h->shard_ctx.reset();
     h->shard_stream = nullptr;
+  });
+}
+
+// ---- K1 sharded over ranks: every rank computes a block of the packed covariance array, the caller all-gathers ----
+int ngicp_covs_shard_begin(ngicp_t* h, int which, double** covs6_dev, size_t* n_points) {
+  return guarded(h, [&] {
+    if ((which != 0 && which != 1) || !covs6_dev || !n_points) throw ArgError{NGICP_ERR_ARG, "bad argument"};
+    Slot& slot = which ? h->tgt : h->src;
+    ensure_slot_ready(h, slot, which ? "target" : "source");
+    CovSet& cs = h->shard_covs[which];
+    cs.data = acquire_buf(h, h->device, slot.dev->n * 6 * sizeof(double));
+    cs.n = slot.dev->n;
+    cs.order = slot.dev;
+    HIP_TRY(hipStreamSynchronize(h->stream));  // (the index build; the caller may use a stream of its own from here on)
+    *covs6_dev = cs.data->as<double>();
+    *n_points = cs.n;
+  });
+}
+int ngicp_covs_shard_compute(ngicp_t* h, int which, size_t lo, size_t hi, void* stream_or_null) {
+  return guarded(h, [&] {
+    if (which != 0 && which != 1) throw ArgError{NGICP_ERR_ARG, "bad argument"};
+    CovSet& cs = h->shard_covs[which];
+    Slot& slot = which ? h->tgt : h->src;
+    if (!cs.data || cs.order.get() != slot.dev.get()) throw ArgError{NGICP_ERR_STATE, "ngicp_covs_shard_begin not called for this cloud"};
+    if (lo > hi || hi > cs.n) throw ArgError{NGICP_ERR_ARG, "block outside the cloud"};
+    launch_cov_range(h, *slot.dev, cs.data->as<double>(), lo, hi, stream_or_null ? (hipStream_t)stream_or_null : h->stream);
+    HIP_TRY(hipGetLastError());
+  });
+}
+int ngicp_covs_shard_commit(ngicp_t* h, int which) {
+  return guarded(h, [&] {
+    if (which != 0 && which != 1) throw ArgError{NGICP_ERR_ARG, "bad argument"};
+    CovSet& cs = h->shard_covs[which];
+    Slot& slot = which ? h->tgt : h->src;
+    if (!cs.data || cs.order.get() != slot.dev.get()) throw ArgError{NGICP_ERR_STATE, "ngicp_covs_shard_begin not called for this cloud"};
+    (which ? h->tgt_covs : h->src_covs) = cs;
+    cs.clear();
   });
 }
 

@@ -291,12 +291,12 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
 enum { REG_NONE = 0, REG_MIN_EIG = 1, REG_NORMALIZED_MIN_EIG = 2, REG_PLANE = 3, REG_FROBENIUS = 4 };
 
 template <int K, int WL>
-__global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int n, int k, int reg,
+__global__ void __launch_bounds__(kKnnBlock) k_covariances(const float4* __restrict__ sorted, const int* __restrict__ cell_start, Grid g, int first, int n, int k, int reg,
                                                             double* __restrict__ covs6) {
   __shared__ int lds_bounds[36 * kKnnPairs];
   constexpr int H = K / 2;
   const int lane = threadIdx.x & 63, sub = threadIdx.x & 1, pair = threadIdx.x >> 1;
-  const int i = blockIdx.x * kKnnPairs + pair;  // a pair of lanes per point
+  const int i = first + blockIdx.x * kKnnPairs + pair;  // a pair of lanes per point; points [first, n) of the sorted cloud (a rank's block when K1 is sharded)
   if (i >= n) return;
   const float4 q = sorted[i];
   PairTopK<K> top;

@@ -51,7 +51,8 @@ class Stats(C.Structure):
     _fields_ = [("align_ms", C.c_double), ("loop_ms", C.c_double), ("pass_ms_total", C.c_double), ("passes", C.c_int),
                 ("outer_iterations", C.c_int), ("lm_trials", C.c_int), ("mean_candidates", C.c_double), ("valid_fraction", C.c_double),
                 ("index_build_ms", C.c_double), ("covariance_ms", C.c_double), ("upload_ms", C.c_double), ("voxel_size", C.c_double),
-                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong), ("staged_fraction", C.c_double), ("submap_ms", C.c_double)]
+                ("grid_dims", C.c_int * 3), ("lanes_per_query", C.c_int), ("passes_timed", C.c_int), ("n_src", C.c_longlong), ("n_tgt", C.c_longlong), ("staged_fraction", C.c_double), ("submap_ms", C.c_double),
+                ("device_allocs", C.c_longlong), ("host_wait_spins", C.c_longlong)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -72,7 +73,7 @@ EXPORTS = [
     "ngicp_keyframe_add", "ngicp_keyframe_add_transformed", "ngicp_keyframe_add_transformed_filtered", "ngicp_keyframe_count", "ngicp_keyframe_size", "ngicp_keyframe_clear",
     "ngicp_submap_set", "ngicp_get_target_points", "ngicp_transform_source", "ngicp_transform_cloud", "ngicp_measure_copy_bandwidth",
     "ngicp_preprocess_scan", "ngicp_set_source_preprocessed", "ngicp_map_add", "ngicp_map_voxel_filter", "ngicp_map_size", "ngicp_map_get",
-    "ngicp_map_clear", "ngicp_math_selftest",
+    "ngicp_map_clear", "ngicp_math_selftest", "ngicp_set_host_wait", "ngicp_covs_shard_begin", "ngicp_covs_shard_compute", "ngicp_covs_shard_commit",
 ]
 
 _lib = None
@@ -98,6 +99,10 @@ def load_library() -> C.CDLL:
     L.ngicp_version.restype = C.c_char_p
     L.ngicp_set_params.argtypes = [vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
     L.ngicp_set_tuning.argtypes = [vp, C.c_double, C.c_int]
+    L.ngicp_set_host_wait.argtypes = [vp, C.c_int]
+    L.ngicp_covs_shard_begin.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.ngicp_covs_shard_compute.argtypes = [vp, C.c_int, C.c_size_t, C.c_size_t, vp]
+    L.ngicp_covs_shard_commit.argtypes = [vp, C.c_int]
     for n in ("ngicp_set_source", "ngicp_register_source", "ngicp_set_target"):
         getattr(L, n).argtypes = [vp, c_f32p, C.c_size_t, C.c_size_t, C.c_uint64]
     for n in ("ngicp_clear_source", "ngicp_clear_target", "ngicp_swap_source_target", "ngicp_compute_source_covs",
@@ -224,6 +229,10 @@ class NanoGICP:
     def setSearchMethodSource(self, tree=None, force_no_recompute=True): pass
     def setSearchMethodTarget(self, tree=None, force_no_recompute=True): pass
     def setDebugPrint(self, on: bool): self._debug = bool(on)
+
+    def setHostWaitMode(self, mode: int):
+        """0: the calling thread polls the device without giving its core up (default); 1: it yields between polls."""
+        self._ck(self._L.ngicp_set_host_wait(self._h, int(mode)))
 
     def setTuning(self, voxel_size: float = 0.0, lanes_per_query: int = 0):
         self._ck(self._L.ngicp_set_tuning(self._h, float(voxel_size), int(lanes_per_query)))
@@ -491,6 +500,19 @@ class NanoGICP:
         v = C.c_double(0)
         self._ck(self._L.ngicp_measure_copy_bandwidth(self._h, int(nbytes), int(reps), C.byref(v)))
         return v.value
+
+    # ---- covariances sharded over ranks (K1 with an all-gather of the packed covariances) ----
+    def covsShardBegin(self, which: int):
+        """-> (device pointer of the packed [n][6] FP64 set, n).  which: 0 source, 1 target."""
+        ptr = C.c_void_p(0); n = C.c_size_t(0)
+        self._ck(self._L.ngicp_covs_shard_begin(self._h, int(which), C.byref(ptr), C.byref(n)))
+        return ptr.value, n.value
+
+    def covsShardCompute(self, which: int, lo: int, hi: int, stream: int = 0):
+        self._ck(self._L.ngicp_covs_shard_compute(self._h, int(which), int(lo), int(hi), C.c_void_p(stream) if stream else None))
+
+    def covsShardCommit(self, which: int):
+        self._ck(self._L.ngicp_covs_shard_commit(self._h, int(which)))
 
     # ---- point-sharded stepping (SURVEY.md §8e.2); buffers are raw device pointers ----
     def sharded_begin(self, guess=None):

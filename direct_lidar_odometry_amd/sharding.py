@@ -67,6 +67,53 @@ def gather_results(T_local: list[np.ndarray], dist, device=None):
     return [o[: int(c.item())].cpu().numpy() for o, c in zip(outs, counts)]
 
 
+class _DevicePointer:
+    """A raw device allocation as something torch can alias (CUDA array interface)."""
+    def __init__(self, ptr: int, n_doubles: int):
+        self.__cuda_array_interface__ = {"shape": (int(n_doubles),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_doubles(ptr: int, n_doubles: int, torch_device):
+    """torch tensor aliasing `n_doubles` FP64 values at device pointer `ptr` (no copy)."""
+    import torch
+    return torch.as_tensor(_DevicePointer(ptr, n_doubles), device=torch.device(torch_device))
+
+
+def sharded_covariances(engine, which: int, dist, torch_device):
+    """K1 sharded over ranks (the loop being split is impl/nano_gicp_impl.hpp:309-354).  `engine` holds the WHOLE
+    cloud as its source (which = 0) or target (which = 1) on every rank - the k-NN of a point looks at all of it, and the index
+    build is deterministic, so the packed [n][6] FP64 covariance array has the same layout everywhere.  Rank r computes the rows of
+    the sorted positions shard_bounds(n, world, r) in place, the blocks are exchanged (one all_gather_into_tensor when they are of
+    equal size, else one broadcast per rank), and the set is committed as the cloud's covariances.  The engine offers
+    covsShardBegin / covsShardTensor / covsShardCompute / covsShardCommit (the HIP engine's NanoGICP, or a stand-in)."""
+    import contextlib
+    import torch
+    dev = torch.device(torch_device)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ptr, n = engine.covsShardBegin(which)
+    covs = engine.covsShardTensor(which, dev) if hasattr(engine, "covsShardTensor") else device_doubles(ptr, n * 6, dev)
+    lo, hi = shard_bounds(n, world, rank)
+    if dev.type == "cuda":  # engine kernel and collective ordered on one (non-null) stream, as in sharded_align
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        ctx, stream = torch.cuda.stream(side), side.cuda_stream
+    else:
+        side, ctx, stream = None, contextlib.nullcontext(), 0
+    with ctx:
+        engine.covsShardCompute(which, lo, hi, stream)
+        if world > 1:
+            if n % world == 0:
+                dist.all_gather_into_tensor(covs, covs[lo * 6:hi * 6].clone())
+            else:
+                for r in range(world):
+                    a, b = shard_bounds(n, world, r)
+                    dist.broadcast(covs[a * 6:b * 6], src=r)
+        if side is not None:
+            side.synchronize()
+    engine.covsShardCommit(which)
+    return n
+
+
 MAX_SHARDED_PASSES = 64 * 10 + 8  # max_iterations x lm_max_iterations of the reference's defaults, plus the reporting lag
 
 

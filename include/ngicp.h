@@ -75,6 +75,11 @@ int ngicp_set_params(ngicp_t* h, int k, double max_corr_dist, int max_iter, doub
  * depend on it beyond the summation order.  `lanes_per_query` is accepted for ABI stability (0, 1, 2, 4, 8 or 16) and
  * ignored: the per-iteration kernel is built for 32-query batches with 2 lanes per query. */
 int ngicp_set_tuning(ngicp_t* h, double voxel_size, int lanes_per_query);
+/* How the calling thread waits for the device inside ngicp_align(): 0 (default) polls the solver's progress word without giving
+ * the core up (lowest latency: a 100k -> 500k alignment is ~1 ms); 1 yields the core between polls (sched_yield: for hosts
+ * that run other work on the same core - the node's other callbacks in DLO's AsyncSpinner, src/dlo/odom_node.cc:27).
+ * Results do not depend on it. */
+int ngicp_set_host_wait(ngicp_t* h, int mode);
 
 /* --- clouds --------------------------------------------------------------- */
 /* setInputSource impl/nano_gicp_impl.hpp:121-129: store cloud, (re)build index, clear source covs. */
@@ -168,6 +173,9 @@ typedef struct ngicp_stats {
   long long n_src, n_tgt;   /* cloud sizes of the last align */
   double staged_fraction;   /* fraction of queries served through the LDS row index of their batch region */
   double submap_ms;         /* host wall time of the last ngicp_submap_set() that rebuilt the target (enqueue + index build) */
+  long long device_allocs;  /* hipMalloc calls made by this process's engine buffers so far (a call that grows a buffer in the middle of
+                               a frame shows up as a latency outlier: two readings around a call attribute it) */
+  long long host_wait_spins; /* polls of the solver's progress word during the last ngicp_align() (busy or yielding, see below) */
 } ngicp_stats;
 int ngicp_get_stats(ngicp_t* h, ngicp_stats* out);
 /* HIP-event timing of the k_gicp_pass launches inside align (two event records per timed launch; off by default).
@@ -188,6 +196,17 @@ int ngicp_sharded_begin(ngicp_t* h, const float guess_colmajor[16]);
 int ngicp_sharded_pass(ngicp_t* h, double* sums32_dev, void* hip_stream_or_null);
 int ngicp_sharded_step(ngicp_t* h, const double* sums32_dev, void* hip_stream_or_null, int* done);
 int ngicp_sharded_finish(ngicp_t* h, float T_out_colmajor[16], int* converged, int* nr_iterations, double final_hessian_colmajor[36]);
+/* K1 sharded the same way ("K1 shards the same way with an all-gather of the packed covariances"; the loop being split is
+ * impl/nano_gicp_impl.hpp:309-354).  Every rank holds the whole cloud (the k-NN of a point looks at all of it) and the same index
+ * (the build is deterministic), so the packed covariance array [n][6] FP64 has the same layout on every rank: rank r computes the
+ * rows of the points at sorted positions [lo, hi) of the source (which = 0) or target (which = 1) cloud in place, the caller
+ * all-gathers the blocks (RCCL through torch.distributed on the device pointer *covs6_dev, n * 6 doubles) and commits the set.
+ *   ngicp_covs_shard_begin    allocates the set (uncommitted: align() will not use it) and returns its device pointer and n
+ *   ngicp_covs_shard_compute  computes the block [lo, hi) (sorted positions) on the handle's stream, or on `stream` if given
+ *   ngicp_covs_shard_commit   the set becomes the cloud's covariances (as after ngicp_compute_*_covs) */
+int ngicp_covs_shard_begin(ngicp_t* h, int which, double** covs6_dev, size_t* n_points);
+int ngicp_covs_shard_compute(ngicp_t* h, int which, size_t lo, size_t hi, void* hip_stream_or_null);
+int ngicp_covs_shard_commit(ngicp_t* h, int which);
 
 /* --- device-resident keyframe store + submap assembly ------------ */
 /* DLO keeps every keyframe twice on the host: its cloud (`keyframes`, src/dlo/odom.cc:1166) and its covariances

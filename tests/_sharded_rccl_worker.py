@@ -44,6 +44,14 @@ def main():
                             "converged": [bool(e.converged_), bool(full.converged_)],
                             "max_abs_diff": float(np.abs(T - full.getFinalTransformation()).max())})
         e.close()
+    # K1 sharded (world size 1: the whole array is this rank's block; the tensor aliases the engine's device buffer)
+    a = NanoGICP(); a.setCorrespondenceRandomness(10); a.setInputSource(w.source)
+    n_cov = sharding.sharded_covariances(a, 0, dist, "cuda:0")
+    b = NanoGICP(); b.setCorrespondenceRandomness(10); b.setInputSource(w.source); b.calculateSourceCovariances()
+    out["covs"] = {"n": int(n_cov), "bit_equal": bool(np.array_equal(a.getSourceCovariances(), b.getSourceCovariances()))}
+    ptr, nn = a.covsShardBegin(0)
+    view = sharding.device_doubles(ptr, nn * 6, "cuda:0")
+    out["covs"]["alias_len"] = int(view.numel())
     out["backend"] = dist.get_backend()
     out["world_size"] = dist.get_world_size()
     dist.destroy_process_group()

@@ -34,3 +34,5 @@ def test_sharded_align_over_rccl_world_size_1(hip_lib):
         # one rank: the all-reduce is the identity, so the stepped alignment must reproduce align() to the last bit
         assert r["bit_equal"], r
         assert r["iters"][0] == r["iters"][1] and r["converged"][0] == r["converged"][1]
+    # K1 sharded over the same group: the engine's buffer aliased by a torch tensor, block computed in place, committed
+    assert out["covs"]["n"] == 20000 and out["covs"]["bit_equal"] and out["covs"]["alias_len"] == 6 * 20000

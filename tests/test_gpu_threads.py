@@ -68,3 +68,22 @@ def test_handles_on_concurrent_threads_give_the_serial_results(ng):
             for a, b in zip(poses, serial[t][0]):
                 assert np.array_equal(a, b)
             assert np.array_equal(covs, serial[t][1])
+
+
+def test_yielding_host_wait_gives_the_same_alignment(ng=None):
+    """ngicp_set_host_wait(1): the calling thread yields its core between polls of the solver's progress word instead of spinning
+    on it (DLO's callbacks share an AsyncSpinner's threads, src/dlo/odom_node.cc:27).  How the host waits cannot change what the
+    device computes."""
+    import numpy as np
+    from direct_lidar_odometry_amd import clouds, nano_gicp
+    w = clouds.scan_to_scan(20_000)
+    out = []
+    for mode in (0, 1):
+        g = nano_gicp.NanoGICP(); g.setHostWaitMode(mode); g.setMaxCorrespondenceDistance(1.0)
+        g.setInputSource(w.source); g.setInputTarget(w.target); g.align()
+        out.append((g.getFinalTransformation().copy(), g.nr_iterations_, g.stats()["host_wait_spins"]))
+        g.close()
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert out[0][2] >= 0 and out[1][2] >= 0
+    with __import__("pytest").raises(nano_gicp.NgicpError):
+        g2 = nano_gicp.NanoGICP(); g2.setHostWaitMode(7)

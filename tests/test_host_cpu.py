@@ -255,3 +255,64 @@ def test_two_rank_gloo_point_sharded_align(oracle_mod):
         assert dt <= 1e-6 and dr <= 1e-6, (dt, dr)         # the sharded sums differ from the unsharded ones only in summation order
         assert nit == it_ref and conv
         assert steps == (it_ref + 1) + 1 + _OracleShardEngine.LAG  # one pass per LM trial + the first linearisation + the reporting lag
+
+
+class _OracleCovShardEngine:
+    """Stand-in for the HIP engine's covsShard* protocol on the CPU: the oracle computes the covariances of a block of points
+    against the WHOLE cloud (per-point k-NN), the packed [n][6] rows live in a numpy array that torch aliases."""
+
+    def __init__(self, orc, cloud, k):
+        self.orc, self.cloud, self.k = orc, np.ascontiguousarray(cloud, np.float32), k
+        self.full = orc.covariances(self.cloud, k, 3, 1)  # (what a rank would compute for its block; sliced below)
+        self.rows = np.zeros((len(cloud), 6))
+        self.committed = False
+
+    def covsShardBegin(self, which):
+        return self.rows.ctypes.data, len(self.rows)
+
+    def covsShardTensor(self, which, dev):
+        import torch
+        return torch.from_numpy(self.rows.reshape(-1))
+
+    def covsShardCompute(self, which, lo, hi, stream=0):
+        c = self.full[lo:hi]
+        self.rows[lo:hi] = np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
+
+    def covsShardCommit(self, which):
+        self.committed = True
+
+
+def _gloo_sharded_covs_worker(rank, world, port, n, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from direct_lidar_odometry_amd import sharding as sh
+        from oracle import oracle as orc
+        with np.load(os.path.join(ROOT, "tests", "golden", "ngicp_small.npz")) as z:
+            cloud = z["target"][:n]
+        e = _OracleCovShardEngine(orc, cloud, 10)
+        got_n = sh.sharded_covariances(e, 1, dist, torch.device("cpu"))
+        c = e.full
+        want = np.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], axis=1)
+        q.put((rank, got_n, e.committed, bool(np.array_equal(e.rows, want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1000, 1001])  # equal blocks (one all-gather) and ragged blocks (one broadcast per rank)
+def test_two_rank_gloo_sharded_covariances(oracle_mod, n):
+    """sharding.sharded_covariances (K1 split over ranks) over gloo with 2 ranks: each computes its block of the
+    packed covariance array, the blocks are exchanged, both ranks end with the complete, identical set."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_sharded_covs_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, got_n, committed, equal in res:
+        assert got_n == n and committed and equal, (rank, got_n, committed, equal)
