@@ -374,11 +374,13 @@ Grid make_grid(const float mn[3], const float mx[3], double h, int max_cells) {
 
 // occ_host: where to put sum(count^2) (synchronous read-back), or null.  occ_device_only: compute it into h->occ but leave it
 // on the device (the caller reads it later, when it synchronises anyway).
-void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_host, bool occ_device_only = false) {
+// stride > 1: an occupancy ESTIMATE from every stride-th point (the cell-start table written is then meaningless)
+void count_and_scan(ngicp* h, DeviceCloud& dc, int n, unsigned long long* occ_host, bool occ_device_only = false, int stride = 1) {
   const Grid& g = dc.grid;
   h->counts.ensure((size_t)(g.ncells + 1) * sizeof(int));
   HIP_TRY(hipMemsetAsync(h->counts.p, 0, (size_t)(g.ncells + 1) * sizeof(int), h->stream));
-  hipLaunchKernelGGL(k_cell_count, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), n, g, h->keys.as<int>(), h->counts.as<int>());
+  hipLaunchKernelGGL(k_cell_count, dim3(pick_blocks((size_t)(n / stride + 1), 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), n, g, h->keys.as<int>(), h->counts.as<int>(),
+                     h->fill.as<int>(), stride);
   const int ntiles = (g.ncells + kScanTile - 1) / kScanTile;
   h->tile_sums.ensure((size_t)ntiles * sizeof(int));
   h->tile_sq.ensure((size_t)ntiles * sizeof(unsigned long long));
@@ -460,11 +462,14 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
   }
   dc->grid = make_grid(mn, mx, hh, max_cells);
   unsigned long long occ = 0;
+  h->fill.ensure(n * sizeof(int));  // (arrival rank of every point inside its cell: k_cell_count -> k_cell_scatter)
   // with a memoised voxel the occupancy is only checked AFTER the build (it corrects the memo for the next cloud): the
   // read-back then rides on the build's final synchronisation instead of stalling the pipeline here
   count_and_scan(h, *dc, ni, (auto_h && !memo_hit) ? &occ : nullptr, auto_h && memo_hit);
   if (auto_h && !memo_hit) {
-    // refine the voxel edge until the mean occupancy seen by a random point (sum c^2 / n) is near the target
+    // the first cloud of a size class: refine the voxel edge until the mean occupancy seen by a random point (sum c^2 / n) is near
+    // the target.  (Round 3 tried estimating it from every 8th / 32nd point: consecutive points of a LiDAR ring share their cells, a
+    // strided sample is not a thinned copy of the cloud, and the estimate settled on cells 2.4x too small - measured, withdrawn.)
     for (int it = 0; it < 4; ++it) {
       const double lam = (double)occ / (double)n;
       const double ratio = h->target_occupancy / std::max(lam, 1.0);
@@ -477,13 +482,11 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
     }
   }
   const Grid& g = dc->grid;
-  h->fill.ensure((size_t)(g.ncells + 1) * sizeof(int));
-  HIP_TRY(hipMemsetAsync(h->fill.p, 0, (size_t)(g.ncells + 1) * sizeof(int), h->stream));
   dc->sorted.ensure((n + 2 * kSortedPad) * sizeof(float4));
   hipLaunchKernelGGL(k_fill_sentinels, dim3(1), dim3(2 * kSortedPad), 0, h->stream, dc->sorted.as<float4>(), ni);
   dc->perm.ensure(n * sizeof(int));
-  hipLaunchKernelGGL(k_cell_scatter, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), h->keys.as<int>(), ni, dc->cells(),
-                     h->fill.as<int>(), h->tmp.as<float4>());
+  hipLaunchKernelGGL(k_cell_scatter, dim3(pick_blocks(n, 256, 2048)), dim3(256), 0, h->stream, h->unsorted.as<float4>(), h->keys.as<int>(), h->fill.as<int>(), ni, dc->cells(),
+                     h->tmp.as<float4>());
   hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cells(), dc->pts(),
                      dc->perm.as<int>());
   dc->sorted3.ensure((n + 2 * kSortedPad) * sizeof(Xyz));

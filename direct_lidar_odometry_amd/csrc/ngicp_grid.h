@@ -112,15 +112,24 @@ __global__ void __launch_bounds__(256) k_unpack_bbox(const unsigned char* __rest
   }
 }
 
-// histogram of points per cell; keys[i] = linear cell of point i
-__global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ pts, int n, Grid g, int* __restrict__ keys, int* __restrict__ counts) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+// histogram of points per cell; keys[i] = linear cell of point i, rank[i] = how many points of that cell arrived before it (the
+// returned value of the atomic: the scatter then needs no second round of atomics; the arrival order is arbitrary and is replaced by
+// k_cell_rank's (x, index) order).  stride > 1: only every stride-th point is counted (occupancy estimates while the voxel edge is
+// being chosen; no keys / ranks are written then).
+__global__ void __launch_bounds__(256) k_cell_count(const float4* __restrict__ pts, int n, Grid g, int* __restrict__ keys, int* __restrict__ counts, int* __restrict__ rank,
+                                                     int stride) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; (long long)t * stride < n; t += gridDim.x * blockDim.x) {
+    const int i = t * stride;
     float4 p = pts[i];
     int cx, cy, cz;
     cell_coords(g, p.x, p.y, p.z, cx, cy, cz);
     int c = cell_linear(g, cx, cy, cz);
-    keys[i] = c;
-    atomicAdd(&counts[c], 1);
+    if (stride == 1) {
+      keys[i] = c;
+      rank[i] = atomicAdd(&counts[c], 1);
+    } else {
+      atomicAdd(&counts[c], 1);
+    }
   }
 }
 
@@ -325,14 +334,10 @@ __global__ void __launch_bounds__(kScanBlock) k_scan2_apply(const int* __restric
   }
 }
 
-// scatter into cell segments (arbitrary order inside a cell)
-__global__ void __launch_bounds__(256) k_cell_scatter(const float4* __restrict__ pts, const int* __restrict__ keys, int n, const int* __restrict__ cell_start,
-                                                       int* __restrict__ fill, float4* __restrict__ tmp) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    int c = keys[i];
-    int pos = cell_start[c] + atomicAdd(&fill[c], 1);
-    tmp[pos] = pts[i];
-  }
+// scatter into cell segments (arrival order inside a cell: see k_cell_count)
+__global__ void __launch_bounds__(256) k_cell_scatter(const float4* __restrict__ pts, const int* __restrict__ keys, const int* __restrict__ rank, int n,
+                                                       const int* __restrict__ cell_start, float4* __restrict__ tmp) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) tmp[cell_start[keys[i]] + rank[i]] = pts[i];
 }
 
 // make the order inside each cell deterministic AND useful: rank by (x, original index).  Cells of a row are

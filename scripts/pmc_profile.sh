@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 profiles of one workload (scripts/prof_c3.py <reps> <cfg>): kernel trace + stats, then PMC counters in their own
-# passes (no tracing domains mixed in, as the pool requires).  usage: scripts/pmc_profile.sh <cfg: c3|c2|c5> [reps]
+# passes.  Every PMC pass also carries --kernel-trace (allowed next to --pmc; no sys / runtime / hip / hsa / memory-copy tracing is
+# mixed in, as the pool requires): scripts/pmc_summary.py joins counter rows to launch durations by dispatch id inside each pass.  usage: scripts/pmc_profile.sh <cfg: c3|c2|c5> [reps]
 # Output: gpurun_out/pmc_<cfg>/<pass>/...; summarise with scripts/pmc_summary.py <cfg>.
 set -o pipefail
 CFG=${1:-c3}; REPS=${2:-3}

@@ -1,9 +1,9 @@
-"""gpurun_out/pmc_<cfg>/* (scripts/pmc_profile.sh) -> profiles/r02_<cfg>_kernel_stats.csv + profiles/r02_<cfg>_pass_counters.json.
-usage: python scripts/pmc_summary.py <cfg> [round tag, default r02]"""
+"""gpurun_out/pmc_<cfg>/* (scripts/pmc_profile.sh) -> profiles/<tag>_<cfg>_kernel_stats.csv + profiles/<tag>_<cfg>_pass_counters.json.
+usage: python scripts/pmc_summary.py <cfg> [round tag, default r03]"""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", f"pmc_{cfg}")
 DST = os.path.join(ROOT, "profiles")
 os.makedirs(DST, exist_ok=True)
@@ -33,10 +33,22 @@ cov = {k: sum(v) / len(v) for k, v in durs.items() if "k_covariances" in k}
 
 
 def pmc(name):
+    """Counter rows of one PMC pass, restricted to the WORKING launches of each kernel: every pass carries its own kernel trace, so
+    a counter row is joined to its dispatch's duration by dispatch id and kept when the launch ran longer than 15 us (the launches
+    enqueued after the alignment has finished return at once).  (Round 2 dropped the smallest third of the values instead, which
+    also threw genuine launches away and biased the means upward.)"""
     f = one(f"{name}/**/*counter_collection.csv")
+    t = one(f"{name}/**/*kernel_trace.csv")
+    dur = {}
+    if t:
+        for r in csv.DictReader(open(t)):
+            dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if f:
         for r in csv.DictReader(open(f)):
+            d = dur.get(r.get("Dispatch_Id"))
+            if d is not None and d <= 15.0 and "k_gicp_pass" in r["Kernel_Name"]:
+                continue
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
@@ -44,9 +56,7 @@ def pmc(name):
 def work_mean(agg, kern_sub, counter):
     for k, v in agg.items():
         if kern_sub in k and counter in v:
-            vals = sorted(v[counter])
-            vals = vals[len(vals) // 3:]  # drop the early-exit launches (smallest third)
-            return sum(vals) / len(vals)
+            return sum(v[counter]) / len(v[counter])
     return None
 
 
