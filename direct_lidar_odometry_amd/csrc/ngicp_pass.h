@@ -1028,6 +1028,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
           code[k] = -1;
           gap[k] = 0.f;
+          bnd[k] = Bounds4{{0, 0, 0, 0}};
           if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
             gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
             if (gap[k] <= lim) {
@@ -1037,27 +1038,33 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           }
         }
         const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
+        // (queue slots from ballots: up to 64 lanes adding 1 to the same LDS word at once was nearly every LDS-busy cycle of the
+        // kernel a conflict cycle - profiles/r02_c3_pass_counters.json: SQ_LDS_BANK_CONFLICT 0.97 M of SQ_ACTIVE_INST_LDS 1.06 M)
+        int ntail = 0;
 #pragma unroll
         for (int k = 0; k < kRowsPerLane; ++k) {
-          if (code[k] < 0) continue;
           const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
-          if (e0 <= s0) continue;
-          const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
-          const int slot = atomicAdd(&S.q_tail, 1);  // at most 32 x 9 units: fits
-          S.unit_q[slot] = grp | (code[k] << 5) | (min(max(m - s0, 0), (1 << 22) - 1) << 9);
-          S.unit_s[slot] = s0;
-          S.unit_e[slot] = e0;
-          S.unit_g[slot] = gap[k];
+          const bool has = code[k] >= 0 && e0 > s0;
+          const unsigned long long hm = __ballot(has);
+          if (has) {
+            const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
+            const int slot = ntail + __popcll(hm & ((1ull << lane) - 1ull));  // at most 32 x 9 units: fits
+            S.unit_q[slot] = grp | (code[k] << 5) | (min(max(m - s0, 0), (1 << 22) - 1) << 9);
+            S.unit_s[slot] = s0;
+            S.unit_e[slot] = e0;
+            S.unit_g[slot] = gap[k];
+          }
+          ntail += __popcll(hm);
         }
+        if (lane == 0) S.q_tail = ntail, S.q_head = 64;  // (lane 0 holds a query whenever the batch has one)
       }
       wave_lds_sync();
       NG_STAMP(16);
       {
         const int tail = S.q_tail;
         unsigned int popped = 0;
-        for (;;) {
-          const int u = atomicAdd(&S.q_head, 1);
-          if (u >= tail) break;
+        // the first 64 units go to the lanes by number; only what is left beyond them is popped from the shared counter
+        for (int u = lane; u < tail; u = tail > 64 ? atomicAdd(&S.q_head, 1) : tail) {
           ++popped;
           const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
           const float gyz = S.unit_g[u];
