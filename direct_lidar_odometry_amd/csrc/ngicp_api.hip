@@ -881,6 +881,30 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   // the launch order the previous align ended with is still a good guess when the source index is the same one
   // (same batches; the costs come mostly from where the batches lie): the first pass then starts sorted as well
   st.order_valid = (h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks) ? 1 : 0;
+  // NGICP_ORDER=xcd (experiment): instead of the cost-sorted launch order, a FIXED order that hands every XCD (blocks b, b + 8, ...
+  // are observed to share one) a contiguous eighth of the Morton-ordered groups: each XCD's L2 then sees an eighth of the target.
+  static const bool xcd_order = std::getenv("NGICP_ORDER") && std::string(std::getenv("NGICP_ORDER")) == "xcd";
+  if (xcd_order) {
+    const int nb = c.nblocks, per = (nb + 7) / 8;
+    std::vector<int> ord((size_t)nb);
+    std::vector<int> lists[8];
+    for (int g = 0; g < nb; ++g) lists[std::min(7, g / per)].push_back(g);
+    size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int b = 0;
+    for (int placed = 0; placed < nb; ++b) {  // block b belongs to XCD b % 8: the next group of that XCD's list, or of the fullest one left
+      int x = b % 8;
+      if (taken[x] >= lists[x].size()) {
+        x = 0;
+        for (int y = 1; y < 8; ++y)
+          if (lists[y].size() - taken[y] > lists[x].size() - taken[x]) x = y;
+      }
+      ord[(size_t)placed++] = lists[x][taken[x]++];
+    }
+    HIP_TRY(hipMemcpyAsync(h->grp_order.p, ord.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    st.order_valid = 1;
+    c.sa.grp_order = nullptr;  // the solver leaves the order alone
+  }
   h->order_src = nullptr;  // set again below, once this align has left a complete order behind
   c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
   // Whether the FIRST pass lists the region rows of every batch (later passes list for the batches that looked beyond ring 1 in the
