@@ -99,8 +99,15 @@ def ms_per_scan_gpu(g, w, reps=50):
     the download of the aligned cloud.  The 500k-point submap (index + covariances) is resident: DLO changes it only when the
     keyframe set changes (odom.cc:827).  `reps` scans after one warm-up: median, p99 and maximum, and for the slowest scan what the
     engine's own timers say (a device allocation in the middle of a frame, the upload, the index build or the loop)."""
+    import gc
     base = [np.ascontiguousarray(w.source + np.float32(1e-4 * (i + 1))) for i in range(8)]  # distinct buffers, like new scans
     t, detail = [], []
+    # (round 2's 38 ms outlier sat OUTSIDE the engine's calls - its own timers read 1.5 ms for that scan: a full collection of the Python
+    # interpreter's garbage collector, tens of milliseconds with torch imported.  The collector is held off while scans are timed; the
+    # engine-side timers of the slowest scan stay in the output so that anything else would show.)
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     for i in range(reps + 1):
         scan = base[i % len(base)]
         a0 = g.stats()["device_allocs"]
@@ -115,10 +122,12 @@ def ms_per_scan_gpu(g, w, reps=50):
             t.append(dt)
             detail.append({"ms": dt, "set_source_ms": (t1 - t0) * 1e3, "upload_ms": s["upload_ms"], "index_build_ms": s["index_build_ms"], "align_call_ms": s["align_ms"],
                            "device_loop_ms": s["loop_ms"], "device_allocs_during": int(s["device_allocs"] - a0), "host_wait_spins": int(s["host_wait_spins"])})
+    if gc_was_on:
+        gc.enable()
     g.setInputSource(w.source)
     g.calculateSourceCovariances()
     worst = max(detail, key=lambda d: d["ms"])
-    return {"median_ms": statistics.median(t), "p99_ms": float(np.percentile(t, 99)), "min_ms": min(t), "max_ms": max(t), "reps": len(t), "slowest_scan": worst,
+    return {"median_ms": statistics.median(t), "p99_ms": float(np.percentile(t, 99)), "min_ms": min(t), "max_ms": max(t), "reps": len(t), "slowest_scan": worst, "python_gc_during_timing": "disabled",
             "includes": "host->device upload of the 100k scan (12 B/pt, pageable), index build, source covariances (k=20), 20 iterations "
                         "(21 fused passes), output transform, device->host download of the aligned cloud; submap resident"}
 
@@ -495,10 +504,12 @@ def main():
     passes = 0
     pass_ms = 0.0
     cand = 0.0
+    import gc
+    gc.collect(); gc.disable()  # (a full collection of the interpreter's garbage collector is tens of milliseconds with torch imported: not inside a 20 ms timed region)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        g.align(w.guess)  # returns after the final pose has been read back (stream-synchronous)
+        g.align(w.guess)  # returns once the solver has written the final pose to pinned host memory
         s = g.stats()
         iters_done += s["outer_iterations"]
         passes += s["passes_timed"]
@@ -506,6 +517,7 @@ def main():
         cand += s["mean_candidates"] * s["passes"]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

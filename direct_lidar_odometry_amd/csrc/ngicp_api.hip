@@ -289,6 +289,8 @@ struct ngicp {
   std::vector<hipEvent_t> prof_events;  // pairs around each pass launch when profiling is on
   int* h_progress = nullptr;  // pinned: {passes done | kProgressDone}, written by the solver (SolveArgs::progress_host)
   LmState* pin_state = nullptr;  // pinned [2]: the state image an align uploads / the one it reads back (no staging copies)
+  LmHot* pin_final = nullptr;    // pinned: the state image the solver writes when an alignment is done (SolveArgs::final_host)
+  DevBuf order_flag, t_first;    // device words: grp_order holds a complete order; 100 MHz stamp of the alignment's first pass
   int hook_valid = 0;     // 1: the linearize hook has produced correspondences; 2: an align has (indices of its last linearisation)
 
   // results of the last align
@@ -696,6 +698,13 @@ void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s, hipEve
       hipExtLaunchKernelGGL((k_gicp_pass_st<3>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, b);
     return;
   }
+  if (a.fused) {  // (the solver in the tail of the launch: a build of its own)
+    if (four)
+      hipExtLaunchKernelGGL((k_gicp_pass<2, 4, true>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, a);
+    else
+      hipExtLaunchKernelGGL((k_gicp_pass<2, 3, true>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, a);
+    return;
+  }
   if (four)
     hipExtLaunchKernelGGL((k_gicp_pass<2, 4>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, a);
   else
@@ -763,6 +772,8 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.dbg_stamps = nullptr;
   a.dbg_qstats = nullptr;
   a.dbg_span = nullptr;
+  a.order_valid = h->order_flag.as<int>();
+  a.t_first = nullptr;
   a.fused = 0;
   h->ticket.ensure(64);
   a.ticket = h->ticket.as<int>();
@@ -791,6 +802,9 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.sums_out = nullptr;
   s.dbg_stamps = nullptr;
   s.progress_host = nullptr;
+  s.final_host = nullptr;
+  s.order_valid = h->order_flag.as<int>();
+  s.t_first = nullptr;
   c.nblocks = nblocks;
   h->stats.lanes_per_query = 2;
   h->stats.voxel_size = T.grid.h;
@@ -810,7 +824,7 @@ void init_state_from_pose(LmState& st, const Pose& x0) {
   }
   st.hot.lambda = -1.0;  // impl/lsq_registration_impl.hpp:92
   st.hot.nu = 2.0;
-  for (int i = 0; i < 6; ++i) st.final_hessian[i * 6 + i] = 1.0;
+  for (int i = 0; i < 6; ++i) st.hot.final_H[i * 6 + i] = 1.0;
 }
 
 Pose pose_from_colmajor_f(const float m[16]) {  // Isometry3d(guess.cast<double>()), impl/lsq_registration_impl.hpp:90
@@ -880,7 +894,9 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   init_state_from_pose(st, pose_from_colmajor_f(guess));
   // the launch order the previous align ended with is still a good guess when the source index is the same one
   // (same batches; the costs come mostly from where the batches lie): the first pass then starts sorted as well
-  st.order_valid = (h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks) ? 1 : 0;
+  // (the flag lives in a device word of its own: the solver sets it when an order is complete, the host only clears it when the
+  // source index or the group count changed - it never has to read it back)
+  if (!(h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks)) HIP_TRY(hipMemsetAsync(h->order_flag.p, 0, sizeof(int), h->stream));
   // NGICP_ORDER=xcd (experiment): instead of the cost-sorted launch order, a FIXED order that hands every XCD (blocks b, b + 8, ...
   // are observed to share one) a contiguous eighth of the Morton-ordered groups: each XCD's L2 then sees an eighth of the target.
   static const bool xcd_order = std::getenv("NGICP_ORDER") && std::string(std::getenv("NGICP_ORDER")) == "xcd";
@@ -902,10 +918,10 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     }
     HIP_TRY(hipMemcpyAsync(h->grp_order.p, ord.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    st.order_valid = 1;
+    const int one = 1;
+    HIP_TRY(hipMemcpy(h->order_flag.p, &one, sizeof(int), hipMemcpyHostToDevice));
     c.sa.grp_order = nullptr;  // the solver leaves the order alone
   }
-  h->order_src = nullptr;  // set again below, once this align has left a complete order behind
   c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
   // Whether the FIRST pass lists the region rows of every batch (later passes list for the batches that looked beyond ring 1 in the
   // pass before): it pays where many queries do (100k -> 500k with DLO's settings: 22 % of the batches, scan-to-submap 0.67 -> 0.64 ms)
@@ -948,6 +964,9 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   const int depth = h->chunk_pairs;
   *h->h_progress = 0;
   c.sa.progress_host = h->h_progress;
+  c.sa.final_host = h->pin_final;
+  c.sa.t_first = h->t_first.as<unsigned long long>();
+  c.pa.t_first = h->t_first.as<unsigned long long>();
   // NGICP_FUSED=1: one dispatch per iteration - the last block of the pass reduces and advances the optimiser (PassArgs::fused).
   // Measured on MI355X (round 3, profiles/r03_fused_solver.txt): bit-identical results, but no faster than the separate launch (c3
   // 46.3 vs 45.4 us per iteration, c5 70 vs 56): the write-through rows come back from memory, not from L2, through ONE CU
@@ -958,7 +977,6 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     c.pa.sa = c.sa;
     HIP_TRY(hipMemsetAsync(h->ticket.p, 0, 64, h->stream));
   }
-  HIP_TRY(hipEventRecord(h->ev_a, h->stream));
   long launched = 0;
   bool finished = (h->p.max_iter <= 0);
   const double t_loop = now_ms();
@@ -976,13 +994,24 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     if (!c.pa.fused) hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     ++launched;
   }
-  HIP_TRY(hipEventRecord(h->ev_b, h->stream));
-  HIP_TRY(hipMemcpyAsync(&h->pin_state[1], h->state.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipGetLastError());
-  st = h->pin_state[1];
   float loop_ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&loop_ms, h->ev_a, h->ev_b));
+  if (finished) {
+    HIP_TRY(hipStreamSynchronize(h->stream));  // (max_iterations <= 0: nothing was launched; the state is the initial one)
+  } else {
+    // The solver writes the final state image into pinned memory and THEN raises the done flag (system-scope release): no copy,
+    // no event, no stream synchronisation - the few launches enqueued ahead return at once behind the host's back, and whatever
+    // this handle enqueues next is ordered behind them on its stream.
+    for (;;) {
+      const int prog = __atomic_load_n(h->h_progress, __ATOMIC_ACQUIRE);
+      if (prog & kProgressDone) break;
+      if (launched >= max_passes && launched - (long)(prog & kProgressMask) <= 0) break;  // (cannot happen: the last possible pass sets done)
+      if ((++spins & (h->host_wait ? 0xfff : 0xfffff)) == 0 && now_ms() - t_loop > 30000.0) throw ArgError{NGICP_ERR_HIP, "the registration loop did not finish within 30 s"};
+      if (h->host_wait) sched_yield(); else __builtin_ia32_pause();
+    }
+    st.hot = *h->pin_final;
+    loop_ms = (float)((double)(st.hot.t_done - st.hot.t_first) * 1e-5);  // 100 MHz ticks -> ms
+  }
+  HIP_TRY(hipGetLastError());
 
   if (stamp_path) {
     std::vector<unsigned long long> hs((size_t)c.nblocks * 4 * kStampStride);
@@ -1030,7 +1059,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   h->converged = st.hot.converged;
   h->nr_iterations = st.hot.nr_iterations;
   for (int r = 0; r < 6; ++r)
-    for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.final_hessian[r * 6 + cc];
+    for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.hot.final_H[r * 6 + cc];
   if (st.hot.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // impl/lsq_registration_impl.hpp:106
   h->trace_host.clear();  // fetched on demand (ngicp_get_lm_trace): a diagnostic should not cost every align a synchronous copy
   h->trace_rows_dev = (size_t)st.hot.n_trace;
@@ -1039,10 +1068,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   ngicp_stats& s = h->stats;
   s.loop_ms = loop_ms;
   if (st.hot.have_lin) h->hook_valid = 2;  // ngicp_get_correspondences: the correspondences of the last adopted linearisation
-  if (st.order_valid) {
-    h->order_src = h->src.dev.get();
-    h->order_groups = c.sa.nblocks;
-  }
+  h->order_src = h->src.dev.get();  // (what the order flag on the device, if set, refers to)
+  h->order_groups = c.sa.nblocks;
   s.passes = st.hot.passes;
   s.outer_iterations = st.hot.nr_iterations + 1;
   s.lm_trials = st.hot.n_trace;
@@ -1151,6 +1178,11 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipEventCreate(&h->ev_cov_b));
     HIP_TRY(hipEventCreateWithFlags(&h->ev_fence, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_state), 2 * sizeof(LmState), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_final), sizeof(LmHot), hipHostMallocDefault));
+    h->order_flag.ensure(64);
+    h->t_first.ensure(64);
+    HIP_TRY(hipMemset(h->order_flag.p, 0, 64));
+    HIP_TRY(hipMemset(h->t_first.p, 0, 64));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));
     *h->h_progress = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_shard_done), kShardSlots * sizeof(int), hipHostMallocDefault));
@@ -1205,6 +1237,7 @@ int ngicp_destroy(ngicp_t* h) {
   for (auto& e : h->prof_events)
     if (e) (void)hipEventDestroy(e);
   if (h->pin_state) (void)hipHostFree(h->pin_state);
+  if (h->pin_final) (void)hipHostFree(h->pin_final);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   if (h->h_shard_done) (void)hipHostFree(h->h_shard_done);
   for (auto& e : h->ev_shard)
@@ -1619,7 +1652,7 @@ int ngicp_sharded_finish(ngicp_t* h, float T_out[16], int* converged, int* nr_it
     h->converged = st.hot.converged;
     h->nr_iterations = st.hot.nr_iterations;
     for (int r = 0; r < 6; ++r)
-      for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.final_hessian[r * 6 + cc];
+      for (int cc = 0; cc < 6; ++cc) h->final_hessian[cc * 6 + r] = st.hot.final_H[r * 6 + cc];
     if (st.hot.lm_failed) std::fprintf(stderr, "lm not converged!!\n");  // impl/lsq_registration_impl.hpp:106
     if (T_out) std::memcpy(T_out, h->final_T, sizeof(h->final_T));
     if (converged) *converged = h->converged;

@@ -21,6 +21,8 @@
 // logic is exactly the reference's (same y0, yi, rho, lambda sequence).  The host never reads back
 // inside the loop: the solver publishes a `done` flag and later launches exit immediately.
 #pragma once
+#include <type_traits>
+
 #include "ngicp_knn.h"
 
 namespace ngk {
@@ -63,12 +65,13 @@ struct LmHot {
   int lm_failed;
   int n_trace;
   int passes;     // passes that did work
+  int pad_;
+  double final_H[36];  // H of the last accepted step, row-major (final_hessian_, impl/lsq_registration_impl.hpp:155,203); identity until then
+  unsigned long long t_first, t_done;  // 100 MHz counter at the start of the alignment's first pass / when the solver set `done`
 };
 struct LmState {
   LmHot hot;
   float xi_f[12];  // float(xi): rows of [R|t], the matrix used for the NN query (impl/nano_gicp_impl.hpp:178)
-  double final_hessian[36];
-  int order_valid;  // the solver has published a group order (heaviest first) for the next pass
 };
 
 struct alignas(4) Xyz { float x, y, z; };
@@ -110,6 +113,9 @@ struct SolveArgs {
   const int* grp_cost;     // [nblocks] in: duration of each group's block in the pass just finished
   unsigned long long* dbg_stamps;  // diagnostic only: [8] s_memtime stamps of the last launch, or null
   int* progress_host;      // pinned host memory, or null: {passes done | kProgressDone} published after every step (mode 0)
+  LmHot* final_host;       // pinned host memory, or null: the state image, written when the alignment is done, BEFORE the done flag goes out
+  int* order_valid;        // device word: the solver has published a group order (heaviest first) for the next pass
+  const unsigned long long* t_first;  // device word the first pass of an alignment stamps (100 MHz counter)
 };
 
 struct PassArgs {
@@ -144,6 +150,8 @@ struct PassArgs {
   unsigned long long* dbg_span;    // diagnostic only: per block {s_memrealtime (10 ns ticks) at entry, at exit, HW_ID | XCC_ID << 32, group}, or null
   // fused solver: the block whose ticket is the last of the grid reduces the group rows and advances the optimiser in the tail of
   // the SAME launch (no second dispatch per iteration).  Rows and costs are then stored write-through and published by the ticket.
+  const int* order_valid;          // device word: grp_order holds a complete order
+  unsigned long long* t_first;     // device word: stamped by the first pass of an alignment (block 0), or null
   int fused;
   int* ticket;   // zero before the launch; the last block puts it back
   SolveArgs sa;
@@ -717,7 +725,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
         if (valid && (m & lt) == 0) ord_pos[sw][cls] = base + __popcll(m);
         wsync();
       }
-      if (sw == 0 && lane == 0) st->order_valid = 1;
+      if (sw == 0 && lane == 0 && a.order_valid) *a.order_valid = 1;
     }
     if (a.dbg_stamps && sw == 0 && lane == 0) a.dbg_stamps[7] = __builtin_amdgcn_s_memtime() - t_ord;
   }
@@ -737,7 +745,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
       NG_SSTAMP(4);
       if (accepted) {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) st->final_hessian[i] = L.H[i];
+        for (int i = 0; i < 36; ++i) L.final_H[i] = L.H[i];
         if (!gn) {
           // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
           double den = 0.0;
@@ -773,14 +781,27 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
       }
     }
   }
-  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag);
-  // issued before the state goes back so that the PCIe write overlaps it
-  if (a.mode == 0 && a.progress_host && lane == 0)
-    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // wave 0 stores the state image back (lane 0's LDS writes are ordered before the other lanes' reads by the fence pair)
+  if (a.mode == 0 && lane == 0 && L.done) {
+    L.t_done = __builtin_amdgcn_s_memrealtime();
+    if (a.t_first) L.t_first = *a.t_first;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool finished_now = a.mode == 0 && L.done != 0;
+  // The end of an alignment goes to the host WITHOUT a copy or a stream synchronisation: the image is written to pinned memory
+  // here, then (system-scope release) the done flag; the host, which polls that word anyway, reads the image as soon as it sees
+  // it - the launches it had enqueued ahead return at once behind its back.
+  if (finished_now && a.final_host) {
+    for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64)
+      __hip_atomic_store(reinterpret_cast<int*>(a.final_host) + w, reinterpret_cast<const int*>(&L)[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __builtin_amdgcn_wave_barrier();
+  }
+  // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag)
+  if (a.mode == 0 && a.progress_host && lane == 0)
+    __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (ordered behind the image by the fence above when done)
   for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
   NG_SSTAMP(6);
 #undef NG_SSTAMP
@@ -797,7 +818,7 @@ constexpr int kStampStride = 24;
     if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * kStampStride + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 
-template <int G, int WPS = NGICP_PASS_WAVES>
+template <int G, int WPS = NGICP_PASS_WAVES, bool FUSED = false>
 __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   constexpr int B = 64 / G;  // queries per wave batch
   // Walk windows (see scan_global_outward), measured with the packed points: the default build, whose launches are as long as their
@@ -807,9 +828,12 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   static_assert(kWin <= kSortedPad, "walk windows may overhang the array by at most the sentinel frame");
   static_assert(B == kBatchQueries, "query batches are built for 32 queries (2 lanes per query)");
   __shared__ double lds[4][kNumSlots];
+  // (FUSED is a build of its own: the solver's reduction keeps 28 sixteen-byte loads in flight per thread, and with it in the kernel
+  // the 4-waves-per-SIMD build spilled 35-38 registers instead of 2 - c5 41.6 -> 48.3 us per pass with the tail never even executed)
+  struct Nothing {};
   union PassShared {
     WaveStage stage[4];
-    SolveShared<256> sv;  // the fused solver (the last block of the grid) works where the search tables were
+    typename std::conditional<FUSED, SolveShared<256>, Nothing>::type sv;  // the fused solver (the last block of the grid) works where the search tables were
   };
   __shared__ PassShared shm;
   __shared__ int last_block;
@@ -847,9 +871,10 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   // index, so the result does not depend on the order in which groups are launched.  That order is the solver's business:
   // it sorts the groups by the duration measured in the previous pass, heaviest first (the grid is ~1.7 waves of blocks
   // deep, and the slowest groups take 2-3x the median: started late they would set the kernel's length).
-  const int group = (a.grp_order && st->order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
+  const int group = (a.grp_order && a.order_valid && *a.order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
   const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
   if (a.dbg_span && threadIdx.x == 0) a.dbg_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();  // (the 100 MHz counter: the same on every CU)
+  if (a.t_first && blockIdx.x == 0 && threadIdx.x == 0 && !st->hot.have_lin) *a.t_first = __builtin_amdgcn_s_memrealtime();
   for (int item = group * 4 + wave; item < a.n_batches; item = a.n_batches) {
     const int2 it = a.batches[item];
     const int qbase = it.x, qcount = it.y, batch = item;
@@ -1305,7 +1330,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
     const int v = threadIdx.x;
     const double val = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
     // fused: write-through (agent-scope store: nothing stays dirty in this XCD's L2, no release fence and no L2 write-back needed)
-    if (a.fused) __hip_atomic_store(a.partials + (size_t)group * kNumSlots + v, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FUSED) __hip_atomic_store(a.partials + (size_t)group * kNumSlots + v, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else a.partials[(size_t)group * kNumSlots + v] = val;
   }
   if (a.dbg_span && threadIdx.x == 0) {
@@ -1316,10 +1341,10 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   }
   if (a.grp_cost && threadIdx.x == 0) {
     const int cost = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
-    if (a.fused) __hip_atomic_store(a.grp_cost + group, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FUSED) __hip_atomic_store(a.grp_cost + group, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else a.grp_cost[group] = cost;
   }
-  if (!a.fused) return;
+  if constexpr (FUSED) {
   // ---- the solver in the tail of the launch (R0's final sum, impl/nano_gicp_impl.hpp:260-267, and LsqRegistration's step,
   //      impl/lsq_registration_impl.hpp:161-208).  Every store of this block that another block will read was made by wave 0 as a
   //      write-through store; wave 0 drains them, then ONE lane takes a ticket (relaxed, agent scope).  The block that draws the
@@ -1343,6 +1368,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   }
   __syncthreads();
   lm_solve_body<256, true>(a.sa, shm.sv);
+  }
 }
 #undef NG_STAMP
 

@@ -161,9 +161,10 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass_st(PassArgs a) {
   const unsigned long long lt = (1ull << lane) - 1ull;
   Stage& S = stage_all[wave];
   NG_STAMP(0);
-  const int group = (a.grp_order && st->order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
+  const int group = (a.grp_order && a.order_valid && *a.order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
   const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
   if (a.dbg_span && threadIdx.x == 0) a.dbg_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+  if (a.t_first && blockIdx.x == 0 && threadIdx.x == 0 && !st->hot.have_lin) *a.t_first = __builtin_amdgcn_s_memrealtime();
   for (int item = group * 4 + wave; item < a.n_batches; item = a.n_batches) {
     const int2 it = a.batches[item];
     const int qbase = it.x, qcount = it.y;
