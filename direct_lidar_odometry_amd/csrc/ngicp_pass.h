@@ -1099,7 +1099,9 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           int up = (int)(unsigned int)k0;
           if (gyz > fminf(ub, a.gate_sq_f)) continue;
           const unsigned int c_before = ncand;
+          const unsigned int steps_before1 = dbg_g1;
           scan_global_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + min((int)((dbg_g1 - steps_before1) & 0xffff), 63), 1);  // diagnostic: window steps per ring-1 unit
           atomicMin(&S.qkey[qs], pack_key(ub, up));
           if (a.dbg_qstats) {
             atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
@@ -1171,7 +1173,9 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
               const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
               const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
               const unsigned int c_before = ncand;
+              const unsigned int steps_before2 = dbg_g2;
               scan_global_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + 64 + min((int)((dbg_g2 - steps_before2) & 0xffff), 63), 1);  // diagnostic: window steps per listed-row unit
               atomicMin(&S.qkey[qs], pack_key(ub, up));
               if (a.dbg_qstats) {
                 atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
