@@ -1,3 +1,4 @@
+// Build and run (on the GPU box; the binary is not kept in the repository):  hipcc --offload-arch=gfx950 -O3 scripts/micro/lat.hip -o scripts/micro/lat && scripts/micro/lat
 // Microbenchmark: dependent random 16-B gathers (pointer chase through a permutation) -> ns per access,
 // for several table sizes and wave counts.  Also a single-lane dependent FP64 FMA chain.
 #include <hip/hip_runtime.h>

@@ -1,3 +1,4 @@
+// Build and run (on the GPU box; the binary is not kept in the repository):  hipcc --offload-arch=gfx950 -O3 scripts/micro/vmem_issue.hip -o scripts/micro/vmem_issue && scripts/micro/vmem_issue
 // Microbenchmark: what does ONE scattered 16-byte gather wave-instruction cost a CU, by number of ACTIVE lanes and by how the
 // 12 loads of a "window" are laid out (12 consecutive float4 per lane = the pass kernel's walk window)?
 // Each wave issues `steps` windows; a window = 12 global_load_dwordx4 at consecutive addresses from a per-lane random base

@@ -519,3 +519,30 @@ def test_device_math_matches_oracle(ng, oracle_mod):
     fulli = np.stack([[[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]] for c in Ci])
     got = np.stack([[[m[0], m[1], m[2]], [m[1], m[3], m[4]], [m[2], m[4], m[5]]] for m in inv])
     assert np.allclose(got, np.linalg.inv(fulli), rtol=1e-8, atol=0)
+
+
+def test_long_thin_cloud_with_a_small_user_voxel(ng, oracle_mod):
+    """the pass kernel packs a listed row as y | z << 16, so a grid may not have more than 65535 rows in y (32767 in z):
+    a 4 km long, 1 m wide cloud with a 5 cm user voxel would have 80 000 - make_grid grows the voxel instead.  The alignment must
+    still equal the oracle's (gate wide enough that rows beyond ring 1 are listed)."""
+    rng = np.random.default_rng(5)
+    n = 20_000
+    tgt = np.c_[rng.uniform(-0.5, 0.5, n), rng.uniform(0.0, 4000.0, n), rng.uniform(-0.5, 0.5, n)].astype(np.float32)
+    T = clouds.make_pose((0.03, -0.05, 0.02), (0.0, 0.0, 0.0003))  # (4 km from the origin: 0.0003 deg are 2 cm)
+    src = clouds.transform_points(np.linalg.inv(T), tgt[::2] + rng.normal(0, 0.005, (n // 2, 3)).astype(np.float32))
+    g, o = ng.NanoGICP(), oracle_mod.OracleGICP()
+    g.setTuning(0.05)
+    for e in (g, o):
+        e.setCorrespondenceRandomness(10); e.setMaxCorrespondenceDistance(0.6)
+        e.setInputSource(src); e.setInputTarget(tgt)
+    g.calculateSourceCovariances(); g.calculateTargetCovariances()
+    s = g.stats()
+    o.setSourceCovariances(g.getSourceCovariances()); o.setTargetCovariances(g.getTargetCovariances())
+    Hg, bg, eg = g.linearize(np.eye(4)); Ho, bo, eo = o.linearize(np.eye(4))
+    cg, sg = g.correspondences(); co, so = o.correspondences()
+    assert g.stats()["grid_dims"][1] < 65536 and g.stats()["voxel_size"] > 0.05
+    assert np.array_equal(cg, co) and np.array_equal(sg[cg >= 0], so[co >= 0]) and (cg >= 0).mean() > 0.5
+    assert abs(eg - eo) <= 1e-9 * abs(eo) and np.abs(Hg - Ho).max() <= 1e-9 * np.abs(Ho).max()
+    g.align(); o.align()
+    _assert_pose_close(g.getFinalTransformation(), o.getFinalTransformation())
+    assert g.nr_iterations_ == o.nr_iterations
