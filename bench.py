@@ -417,9 +417,14 @@ def sharded_c5_leg(ng, dist, world, rank, device, steps=5, warmup=2):
     return out
 
 
+def _free_port() -> int:
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    return port
+
+
 def main_sharded(args):
     """--mode sharded: only the point-sharded c5 alignment (SURVEY.md §8e way 2), at any rank count (N = 1: a single-rank RCCL group)."""
-    import socket
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -429,8 +434,7 @@ def main_sharded(args):
     if "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ and "RANK" in os.environ:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
-        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     from direct_lidar_odometry_amd import build, nano_gicp as ng
     if rank == 0:
         build.build()
@@ -468,8 +472,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    rehearse = world == 1 and os.environ.get("NGICP_BENCH_REHEARSE_SHARDED_EXTRA") == "1"  # the N > 1 extra over a world of one
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" == RCCL on ROCm
+    elif rehearse:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
 
     from direct_lidar_odometry_amd import build, clouds, nano_gicp as ng
     if rank == 0:
@@ -533,7 +540,7 @@ def main():
     it_gpu, conv_gpu = g.nr_iterations_, g.converged_
 
     sharded_extra, force_exit = None, False
-    if world > 1 and not args.no_extras:  # every rank takes part; rank 0 reports (the headline above is already measured)
+    if (world > 1 or rehearse) and not args.no_extras:  # every rank takes part; rank 0 reports (the headline above is already measured)
         # The extra runs in a thread with a wall budget: a collective that never returns must not take the headline line with it
         # (every rank then times out alike, prints / skips, and leaves through os._exit behind the stuck thread).
         import threading
@@ -628,7 +635,7 @@ def main():
     if force_exit:
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0 if parity_ok else 3)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
     if not parity_ok:
         sys.stderr.write("bench.py: PARITY GATE FAILED: the GPU transform differs from the CPU oracle's by more than 1e-4 m / 1e-4 rad\n")
