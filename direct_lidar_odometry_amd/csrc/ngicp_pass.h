@@ -213,6 +213,9 @@ constexpr int kStageMaxGrow = 6;
 #define NGICP_WALK_WINDOW 12
 #endif
 
+#ifndef NGICP_ALIGNED_WINDOWS
+#define NGICP_ALIGNED_WINDOWS 0
+#endif
 constexpr int kWalkWindow = NGICP_WALK_WINDOW;  // points per walk window (one memory round trip); <= kSortedPad
 static_assert(kWalkWindow <= kSortedPad && kWalkWindow % 2 == 0, "walk windows may overhang the array by at most the sentinel frame");
 
@@ -257,7 +260,12 @@ __device__ __forceinline__ void scan_global_outward(const PT* __restrict__ tgt, 
   // alive, then to the left): a window [w, w + 8) of the run, always read in increasing position, so that c[0] / c[7] are its
   // smallest / largest x and, among equal distances, the first one met has the smallest position (strict `<` below).
   // Most walks end after the first window: both neighbours are ruled out by their x-gap alone.
-  int w = m - W / 2, dir = 0, lo = m - W / 2, hi = m - W / 2 + W;  // [lo, hi) has been read
+  // Packed 12-byte points are read FOUR AT A TIME as three 16-byte loads (windows begin at a multiple of four points, i.e. of 48
+  // bytes; the array and its sentinel frame are 16-byte aligned): 12 load instructions per 16-point window instead of 16.  What a
+  // launch queues on is the CU's address path, per wave instruction (scripts/micro/vmem_issue.hip).
+  constexpr bool kQuadLoads = NGICP_ALIGNED_WINDOWS && sizeof(PT) == 12 && W % 4 == 0 && kStep % 4 == 0;
+  const int w0 = kQuadLoads ? ((m - W / 2) & ~3) : m - W / 2;
+  int w = w0, dir = 0, lo = w0, hi = w0 + W;  // [lo, hi) has been read
   int wn = W;  // points of the current window: W around the start, kStep on either side after that.  Measured with W = 12: side windows
                // of 8 / 6 / 4 points examine 8 / 12 / 16 % fewer candidates and cost c3 +3 / +7 / +18 %, c2 +1 / +6 / +16 % in time (more
                // dependent steps) but c5 -3 % (8 points): the build for large grids, bound by what its waves fetch, uses 8
@@ -269,9 +277,27 @@ __device__ __forceinline__ void scan_global_outward(const PT* __restrict__ tgt, 
     // look at the window's last / first point when its right / left end is inside the run.
     const PT* __restrict__ q = tgt + w;  // one address, immediate offsets
     PT c[W];
+    if constexpr (kQuadLoads) {
+      const float4* __restrict__ q4 = reinterpret_cast<const float4*>(q);
+      float4 r[3 * W / 4];
 #pragma unroll
-    for (int j = 0; j < W; ++j)
-      if (j < kStep || wn == W) c[j] = q[j];
+      for (int j = 0; j < 3 * W / 4; ++j)
+        if (j < 3 * kStep / 4 || wn == W) r[j] = q4[j];
+#pragma unroll
+      for (int j = 0; j < W / 4; ++j) {
+        if (j < kStep / 4 || wn == W) {
+          const float4 r0 = r[3 * j], r1 = r[3 * j + 1], r2 = r[3 * j + 2];
+          c[4 * j].x = r0.x; c[4 * j].y = r0.y; c[4 * j].z = r0.z;
+          c[4 * j + 1].x = r0.w; c[4 * j + 1].y = r1.x; c[4 * j + 1].z = r1.y;
+          c[4 * j + 2].x = r1.z; c[4 * j + 2].y = r1.w; c[4 * j + 2].z = r2.x;
+          c[4 * j + 3].x = r2.y; c[4 * j + 3].y = r2.z; c[4 * j + 3].z = r2.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (j < kStep || wn == W) c[j] = q[j];
+    }
     float lb = sqdist(qx, qy, qz, c[0]);
     int lj = 0;
 #pragma unroll
@@ -285,6 +311,82 @@ __device__ __forceinline__ void scan_global_outward(const PT* __restrict__ tgt, 
     ncand += wn;
     ++gsteps;
     const float lim = fminf(best, gate_sq), dr = (wn == W ? c[W - 1].x : c[kStep - 1].x) - qx, dl = qx - c[0].x;
+    const bool more_right = hi < e && !(dr > 0.f && dr * dr + gyz > lim);
+    const bool more_left = lo > s && !(dl > 0.f && dl * dl + gyz > lim);
+    if (dir == 0) go_left = more_left;
+    if (dir >= 0 && more_right) {
+      dir = 1;
+      w = hi;
+      hi += kStep;
+      wn = kStep;
+    } else if (dir >= 0 ? go_left : more_left) {
+      dir = -1;
+      lo -= kStep;
+      w = lo;
+      wn = kStep;
+    } else {
+      break;
+    }
+  }
+}
+
+// The same walk done by the FOUR lanes of a quad on one run: lane ql of the quad reads the points w + ql, w + ql + 4, ... of a window,
+// so one load instruction of the quad covers four consecutive points (48 contiguous bytes) and a W-point window is W / 4 wave
+// instructions instead of W.  The CU's address path is what a launch queues on (a scattered gather costs it ~20 cycles per wave
+// instruction plus ~0.7 per distinct line, scripts/micro/vmem_issue.hip), and a dependent step of a walk is as long as the
+// instructions of the waves queued ahead of it: four times fewer of them per window.  All control flow is quad-uniform; (best, pos)
+// come back identical on the four lanes.  The winner is the same as scan_global_outward's: smallest (distance, position).
+#ifndef NGICP_WALK_LANES
+#define NGICP_WALK_LANES 1
+#endif
+constexpr int kWalkLanes = NGICP_WALK_LANES;  // 1: a lane walks a run by itself; 4: a quad does
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_f(float v) { return __int_as_float(quad_perm_i<CTRL>(__float_as_int(v))); }
+template <int W, int kStep, class PT>
+__device__ __forceinline__ void scan_quad_outward(const PT* __restrict__ tgt, int s, int e, int m, float qx, float qy, float qz, float gyz, float gate_sq,
+                                                  float& best, int& pos, unsigned int& ncand, unsigned int& gsteps, int ql) {
+  static_assert(W % 4 == 0 && kStep % 4 == 0 && kStep >= 4 && kStep <= W, "windows are dealt to the four lanes of a quad");
+  constexpr int PER = W / 4, PERS = kStep / 4;
+  if (e <= s) return;
+  gsteps += 0x10000u;
+  m = min(max(m, s), e - 1);
+  int w = m - W / 2, dir = 0, lo = m - W / 2, hi = m - W / 2 + W;  // [lo, hi) has been read
+  int wn = W;
+  bool go_left = false;
+  for (;;) {
+    const PT* __restrict__ q = tgt + (w + ql);  // (no index clamps: see scan_global_outward)
+    PT c[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (j < PERS || wn == W) c[j] = q[4 * j];
+    float lb = sqdist(qx, qy, qz, c[0]);
+    int lj = 0;
+#pragma unroll
+    for (int j = 1; j < PER; ++j) {
+      if (j < PERS || wn == W) {
+        const float d = sqdist(qx, qy, qz, c[j]);
+        if (d < lb) { lb = d; lj = j; }
+      }
+    }
+    int lp = w + ql + 4 * lj;
+    // the window's first / last x: lane 0's first point, lane 3's last
+    const float xl = quad_perm_f<0x00>(c[0].x), xr = quad_perm_f<0xff>(wn == W ? c[PER - 1].x : c[PERS - 1].x);
+    {
+      const float od = quad_perm_f<0xb1>(lb);
+      const int op = quad_perm_i<0xb1>(lp);
+      if (nn_better(od, op, lb, lp)) { lb = od; lp = op; }
+    }
+    {
+      const float od = quad_perm_f<0x4e>(lb);
+      const int op = quad_perm_i<0x4e>(lp);
+      if (nn_better(od, op, lb, lp)) { lb = od; lp = op; }
+    }
+    if (nn_better(lb, lp, best, pos)) { best = lb; pos = lp; }
+    if (ql == 0) ncand += wn;
+    ++gsteps;
+    const float lim = fminf(best, gate_sq), dr = xr - qx, dl = qx - xl;
     const bool more_right = hi < e && !(dr > 0.f && dr * dr + gyz > lim);
     const bool more_left = lo > s && !(dl > 0.f && dl * dl + gyz > lim);
     if (dir == 0) go_left = more_left;
@@ -984,7 +1086,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
         if (rows <= kStageRows && XS <= kStageXs) {
           // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target, and the
           // row's ring distance from the batch box (rows are listed nearest ring first)
-          int rs[kStageRowsPerLane], rn[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane];
+          int rs[kStageRowsPerLane], rn[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane], rk[kStageRowsPerLane];
 #pragma unroll
           for (int k = 0; k < kStageRowsPerLane; ++k) {
             const int r = lane + 64 * k;
@@ -992,8 +1094,11 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
             const int ry = Y0 + r % wy, rz = Z0 + r / wy;
             const int rb = has ? (rz * g.ny + ry) * g.nx + X0 : 0;
             const int sv = has ? a.tgt_cell_start[rb] : 0, ev = has ? a.tgt_cell_start[rb + XS] : 0;
+            // where the batch box's own x-cells begin / end inside the row (same cache lines): a walk of the row starts between them
+            const int ka = has ? a.tgt_cell_start[rb + (b0x - X0)] : 0, kb = has ? a.tgt_cell_start[rb + (b1x + 1 - X0)] : 0;
             rs[k] = sv;
             rn[k] = ev - sv;
+            rk[k] = min(ka - sv, 0xffff) | (min(kb - sv, 0xffff) << 16);
             rho[k] = max(max(b0y - ry, ry - b1y), max(max(b0z - rz, rz - b1z), 0));
             ryz[k] = ry | (rz << 16);
           }
@@ -1004,7 +1109,7 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
             for (int k = 0; k < kStageRowsPerLane; ++k) {
               const bool on = rn[k] > 0 && rho[k] == lev;
               const unsigned long long m = __ballot(on);
-              if (on) S.live[nlive + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(ryz[k], rn[k], rs[k], 0);  // {y | z << 16, points, first point, -}
+              if (on) S.live[nlive + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(ryz[k], rn[k], rs[k], rk[k]);  // {y | z << 16, points, first point, box x-range inside the row}
               nlive += __popcll(m);
             }
           }
@@ -1081,15 +1186,28 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           }
           ntail += __popcll(hm);
         }
-        if (lane == 0) S.q_tail = ntail, S.q_head = 64;  // (lane 0 holds a query whenever the batch has one)
+        if (lane == 0) S.q_tail = ntail, S.q_head = 64 / kWalkLanes;  // (lane 0 holds a query whenever the batch has one)
       }
       wave_lds_sync();
       NG_STAMP(16);
       {
         const int tail = S.q_tail;
         unsigned int popped = 0;
-        // the first 64 units go to the lanes by number; only what is left beyond them is popped from the shared counter
-        for (int u = lane; u < tail; u = tail > 64 ? atomicAdd(&S.q_head, 1) : tail) {
+        // the first 64 units go to the lanes (the first 16 to the quads) by number; only what is left beyond them is popped from
+        // the shared counter
+        constexpr int kWalkers = 64 / kWalkLanes;
+        const int ql = lane % kWalkLanes;
+        auto next_unit = [&]() {
+          if (tail <= kWalkers) return tail;
+          if constexpr (kWalkLanes == 1) {
+            return atomicAdd(&S.q_head, 1);
+          } else {
+            int nu = 0;
+            if (ql == 0) nu = atomicAdd(&S.q_head, 1);
+            return quad_perm_i<0x00>(nu);
+          }
+        };
+        for (int u = lane / kWalkLanes; u < tail; u = next_unit()) {
           ++popped;
           const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
           const float gyz = S.unit_g[u];
@@ -1100,12 +1218,15 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           if (gyz > fminf(ub, a.gate_sq_f)) continue;
           const unsigned int c_before = ncand;
           const unsigned int steps_before1 = dbg_g1;
-          scan_global_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
-          if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + min((int)((dbg_g1 - steps_before1) & 0xffff), 63), 1);  // diagnostic: window steps per ring-1 unit
-          atomicMin(&S.qkey[qs], pack_key(ub, up));
-          if (a.dbg_qstats) {
-            atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
-            atomicAdd(&S.qstat[qs][1], 1);
+          if constexpr (kWalkLanes == 1) scan_global_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
+          else scan_quad_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1, ql);
+          if (ql == 0) {
+            if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + min((int)((dbg_g1 - steps_before1) & 0xffff), 63), 1);  // diagnostic: window steps per ring-1 unit
+            atomicMin(&S.qkey[qs], pack_key(ub, up));
+            if (a.dbg_qstats) {
+              atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
+              atomicAdd(&S.qstat[qs][1], 1);
+            }
           }
         }
         NG_STAMP(17);
@@ -1153,8 +1274,11 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
           wave_lds_sync();
           {
             const int tail = min(S.q_tail, kUnitCap);
+            const int ql = lane % kWalkLanes;
             for (;;) {
-              const int u = atomicAdd(&S.q_head, 1);
+              int u = 0;
+              if (ql == 0) u = atomicAdd(&S.q_head, 1);
+              if constexpr (kWalkLanes > 1) u = quad_perm_i<0x00>(u);
               if (u >= tail) break;
               const int unit = S.unit_q[u], qs = unit & 31;
               const int4 rec = S.live[unit >> 5];
@@ -1166,20 +1290,21 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
               float ub = __uint_as_float((unsigned int)(k0 >> 32));
               int up = (int)(unsigned int)k0;
               if (gyz > fminf(ub, a.gate_sq_f)) continue;
-              // start where qx sits among the row's three centre cells (one extra round trip, but a much better start
-              // than interpolating over the whole region row: the walk is over the whole row either way)
-              const int cxa = max(ux - 1, 0), cxb = min(ux + 1, g.nx - 1) + 1;
-              const int rowb = ((rec.x >> 16) * g.ny + (rec.x & 0xffff)) * g.nx;
-              const int s0 = a.tgt_cell_start[rowb + cxa], e0 = a.tgt_cell_start[rowb + cxb];
-              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)cxa * g.h)) / ((float)(cxb - cxa) * g.h), 0.f), 1.f);
+              // start where qx sits among the batch box's x-cells of the row (their bounds came with the listing: no round trip
+              // here; the walk is over the whole row either way, the start is only where it begins)
+              const int s0 = rec.z + (rec.w & 0xffff), e0 = rec.z + (int)((unsigned int)rec.w >> 16);
+              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)b0x * g.h)) / ((float)(b1x + 1 - b0x) * g.h), 0.f), 1.f);
               const unsigned int c_before = ncand;
               const unsigned int steps_before2 = dbg_g2;
-              scan_global_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
-              if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + 64 + min((int)((dbg_g2 - steps_before2) & 0xffff), 63), 1);  // diagnostic: window steps per listed-row unit
-              atomicMin(&S.qkey[qs], pack_key(ub, up));
-              if (a.dbg_qstats) {
-                atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
-                atomicAdd(&S.qstat[qs][1], 1 << 16);
+              if constexpr (kWalkLanes == 1) scan_global_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
+              else scan_quad_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2, ql);
+              if (ql == 0) {
+                if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + 64 + min((int)((dbg_g2 - steps_before2) & 0xffff), 63), 1);  // diagnostic: window steps per listed-row unit
+                atomicMin(&S.qkey[qs], pack_key(ub, up));
+                if (a.dbg_qstats) {
+                  atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
+                  atomicAdd(&S.qstat[qs][1], 1 << 16);
+                }
               }
             }
           }
