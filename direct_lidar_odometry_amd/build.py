@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libngicp_hip.so")
 SOURCES = ["ngicp_api.hip", "ngicp_filters.hip"]
-HEADERS = ["ngicp_math.h", "ngicp_grid.h", "ngicp_knn.h", "ngicp_pass.h", "ngicp_pass_st.h", "ngicp_cloudops.h", "ngicp_filters.h", os.path.join("..", "..", "include", "ngicp.h")]
+HEADERS = ["ngicp_pass_group.inc", "ngicp_math.h", "ngicp_grid.h", "ngicp_knn.h", "ngicp_pass.h", "ngicp_pass_st.h", "ngicp_cloudops.h", "ngicp_filters.h", os.path.join("..", "..", "include", "ngicp.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

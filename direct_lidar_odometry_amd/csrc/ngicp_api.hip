@@ -236,6 +236,8 @@ struct Slot {
 };
 
 struct LoopCtx;  // the per-alignment launch arguments (defined with the registration loop)
+constexpr int kMaxPersistPasses = 2048;  // alignments with more possible passes than this take one launch per pass (the ring of views is 512 bytes per pass)
+constexpr int kMaxTickPasses = 1024;  // passes of an alignment whose timestamps the persistent kernel records when profiling is on
 constexpr int kShardSlots = 4, kShardLag = 2;  // point-sharded stepping: the `done` word of step k is read at step k + kShardLag
 
 struct Params {
@@ -281,6 +283,13 @@ struct ngicp {
   // workspaces
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
   int pass_slots = 768;  // blocks of the 3-waves-per-SIMD pass kernel resident on this device at once
+  int persist_slots = 0; // blocks of the persistent pass kernel resident at once (its grid), 0: not available
+  int persist = 0;       // env NGICP_PERSIST=1: ONE launch per alignment (k_gicp_persist).  Exact and complete, but measured no faster than one
+                         // launch per pass: off by default
+  int order_sel = 0;     // which of the two launch-order buffers (and flag words) the next alignment reads
+  DevBuf grp_order_alt;  // the second order buffer: the persistent kernel's solver builds the NEXT alignment's order there
+  DevBuf gen_lines;      // the persistent kernel's release word, kGenLines copies (PassArgs::gen)
+  unsigned long long* pin_ticks = nullptr;  // pinned [2 * kMaxTickPasses]: per pass {last block arrived, next pass released} (profiling)
   double prev_staged_fraction = -1.0;  // share of the queries the previous alignment served through row lists (-1: none yet)
   DevBuf dbg, dbg_q, dbg_s, dbg_span, grp_order, grp_cost, batch_far;
   const void* order_src = nullptr;  // source index / group count the contents of grp_order were built for
@@ -290,7 +299,8 @@ struct ngicp {
   int* h_progress = nullptr;  // pinned: {passes done | kProgressDone}, written by the solver (SolveArgs::progress_host)
   LmState* pin_state = nullptr;  // pinned [2]: the state image an align uploads / the one it reads back (no staging copies)
   LmHot* pin_final = nullptr;    // pinned: the state image the solver writes when an alignment is done (SolveArgs::final_host)
-  DevBuf order_flag, t_first;    // device words: grp_order holds a complete order; 100 MHz stamp of the alignment's first pass
+  DevBuf order_flag, t_first;    // device words {order flag 0, ticket, gen, order flag 1}: grp_order / grp_order_alt holds a complete order, the
+                                 // fused / persistent kernels' ticket and released-pass counter; 100 MHz stamp of the alignment's first pass
   int hook_valid = 0;     // 1: the linearize hook has produced correspondences; 2: an align has (indices of its last linearisation)
 
   // results of the last align
@@ -673,6 +683,11 @@ void set_covs(ngicp* h, Slot& slot, CovSet& cs, const double* in, size_t n, cons
 // ------------------------------------------------------------------------------------------
 // start / stop: events attached to the dispatch itself (they take the kernel's own begin / end timestamps: no extra packets in
 // the stream, unlike hipEventRecord before and after), or null
+std::mutex& persist_mutex(int device) {  // one persistent alignment per device at a time (its grid fills the device and its blocks wait for each other)
+  static std::mutex m[64];
+  return m[(unsigned)device % 64u];
+}
+
 int pass_impl() {
   static const int impl = std::getenv("NGICP_PASS_IMPL") ? std::atoi(std::getenv("NGICP_PASS_IMPL")) : 0;
   return impl;
@@ -733,8 +748,13 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   const int nblocks = std::max(1, (S.n_batches + 3) / 4);  // one block per group of four batches
   h->partials.ensure((size_t)kNumSlots * nblocks * sizeof(double));
   h->grp_order.ensure((size_t)nblocks * sizeof(int));
+  h->grp_order_alt.ensure((size_t)nblocks * sizeof(int));
   h->grp_cost.ensure((size_t)nblocks * sizeof(int));
-  h->state.ensure(sizeof(LmState));
+  {
+    // (the persistent kernel's ring of per-pass views continues behind the state: one 256-byte entry per possible pass)
+    const long ring = (long)std::max(1, h->p.max_iter) * std::max(1, h->p.lm_max_iter) + 2;
+    h->state.ensure(sizeof(LmState) + (ring <= kMaxPersistPasses ? (size_t)ring * kViewWords * sizeof(int) : 0));
+  }
   const int max_rows = std::max(1, h->p.max_iter) * std::max(1, h->p.lm_max_iter) + 1;
   if (h->trace.ensure_grew((size_t)max_rows * kTraceCols * sizeof(double))) h->trace_rows_dev = 0;  // an unfetched trace went with the old buffer
   h->sums.ensure(kPartialStride * sizeof(double));
@@ -743,7 +763,10 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.qpts = S.qpts.as<float4>();
   a.batches = S.batches.as<int2>();
   a.batch_boxes = S.batch_boxes.as<float>();
-  a.grp_order = h->grp_order.as<int>();
+  int* const order_buf[2] = {h->grp_order.as<int>(), h->grp_order_alt.as<int>()};
+  int* const ctl = h->order_flag.as<int>();  // {order flag 0, ticket, gen, order flag 1}
+  int* const order_flag[2] = {ctl, ctl + 3};
+  a.grp_order = order_buf[h->order_sel];
   a.grp_cost = h->grp_cost.as<int>();
   a.n_batches = S.n_batches;
   a.cov_src = covs_for(h, h->src_covs, h->src.dev);
@@ -772,11 +795,15 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.dbg_stamps = nullptr;
   a.dbg_qstats = nullptr;
   a.dbg_span = nullptr;
-  a.order_valid = h->order_flag.as<int>();
+  a.order_valid = order_flag[h->order_sel];
   a.t_first = nullptr;
   a.fused = 0;
-  h->ticket.ensure(64);
-  a.ticket = h->ticket.as<int>();
+  a.persist = 0;
+  a.first_pass = 0;
+  a.max_passes = 0;
+  a.ticket = ctl + 1;
+  h->gen_lines.ensure((size_t)kGenLines * kGenStride * sizeof(int));
+  a.gen = h->gen_lines.as<int>();
   {
     // rings worth staging: enough to cover the distance gate (the search never looks farther), at most kStageMaxGrow
     int need = kStageMaxGrow;
@@ -794,7 +821,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.cfg.lm_init_lambda_factor = h->p.lm_init_lambda_factor;
   s.partials = a.partials;
   s.nblocks = nblocks;
-  s.grp_order = h->grp_order.as<int>();
+  s.grp_order = order_buf[h->order_sel];
   s.grp_cost = h->grp_cost.as<int>();
   s.trace = h->trace.as<double>();
   s.max_trace_rows = max_rows;
@@ -803,8 +830,10 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.dbg_stamps = nullptr;
   s.progress_host = nullptr;
   s.final_host = nullptr;
-  s.order_valid = h->order_flag.as<int>();
+  s.order_valid = order_flag[h->order_sel];
   s.t_first = nullptr;
+  s.persist = 0;
+  s.pass_ticks = nullptr;
   c.nblocks = nblocks;
   h->stats.lanes_per_query = 2;
   h->stats.voxel_size = T.grid.h;
@@ -822,6 +851,9 @@ void init_state_from_pose(LmState& st, const Pose& x0) {
     for (int c = 0; c < 3; ++c) st.xi_f[r * 4 + c] = (float)x0.R[r * 3 + c];
     st.xi_f[r * 4 + 3] = (float)x0.t[r];
   }
+  std::memcpy(&st.view[kViewXi], &st.hot.xi, sizeof(Pose));
+  std::memcpy(&st.view[kViewXiF], st.xi_f, sizeof(st.xi_f));
+  static_assert(sizeof(Pose) == 24 * sizeof(int) && kViewXiF == 24 && sizeof(LmState::xi_f) == 12 * sizeof(int), "LmState::view layout");
   st.hot.lambda = -1.0;  // impl/lsq_registration_impl.hpp:92
   st.hot.nu = 2.0;
   for (int i = 0; i < 6; ++i) st.hot.final_H[i * 6 + i] = 1.0;
@@ -896,7 +928,7 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   // (same batches; the costs come mostly from where the batches lie): the first pass then starts sorted as well
   // (the flag lives in a device word of its own: the solver sets it when an order is complete, the host only clears it when the
   // source index or the group count changed - it never has to read it back)
-  if (!(h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks)) HIP_TRY(hipMemsetAsync(h->order_flag.p, 0, sizeof(int), h->stream));
+  if (!(h->order_src == h->src.dev.get() && h->order_groups == c.sa.nblocks)) HIP_TRY(hipMemsetAsync(h->order_flag.p, 0, 4 * sizeof(int), h->stream));  // (both flags)
   // NGICP_ORDER=xcd (experiment): instead of the cost-sorted launch order, a FIXED order that hands every XCD (blocks b, b + 8, ...
   // are observed to share one) a contiguous eighth of the Morton-ordered groups: each XCD's L2 then sees an eighth of the target.
   static const bool xcd_order = std::getenv("NGICP_ORDER") && std::string(std::getenv("NGICP_ORDER")) == "xcd";
@@ -916,10 +948,10 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       }
       ord[(size_t)placed++] = lists[x][taken[x]++];
     }
-    HIP_TRY(hipMemcpyAsync(h->grp_order.p, ord.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(const_cast<int*>(c.pa.grp_order), ord.data(), (size_t)nb * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int one = 1;
-    HIP_TRY(hipMemcpy(h->order_flag.p, &one, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(const_cast<int*>(c.pa.order_valid), &one, sizeof(int), hipMemcpyHostToDevice));
     c.sa.grp_order = nullptr;  // the solver leaves the order alone
   }
   c.pa.mode = (h->p.optimizer == NGICP_OPT_GAUSS_NEWTON) ? 2 : 3;
@@ -975,12 +1007,91 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   if (fused_env && pass_impl() == 0) {
     c.pa.fused = 1;
     c.pa.sa = c.sa;
-    HIP_TRY(hipMemsetAsync(h->ticket.p, 0, 64, h->stream));
+    HIP_TRY(hipMemsetAsync(c.pa.ticket, 0, sizeof(int), h->stream));
   }
   long launched = 0;
-  bool finished = (h->p.max_iter <= 0);
+  bool finished = (h->p.max_iter <= 0), persist_done = false;
+  float persist_loop_ms = 0.f;
   const double t_loop = now_ms();
   unsigned long spins = 0;
+  // ---- NGICP_PERSIST=1 (experiment, round 3): ONE launch for the whole alignment (k_gicp_persist): as many blocks as are resident
+  //      together, each keeping its groups pass after pass; the last block to finish a pass steps the optimiser and releases the next
+  //      one.  The idea: no second dispatch, no kernel boundaries - and with them no cold caches (a launch boundary drops every L2, and
+  //      ~9 of 10 L2 read requests of a pass go out to the fabric: profiles/r03_c3_pass_counters.json).  Measured (profiles/
+  //      r03_persistent_kernel.txt): bit-identical results; the groups run 4 % faster, but every hop of the grid-wide meeting (rows
+  //      written through, ticket, state, release word, view) is a ~1-2 us round trip to memory, as long as the launches they replace:
+  //      c3 50.7 us per iteration against 48.2, c5 76 against 58 (it has no 4-waves build).  So the default stays one launch per pass.
+  //      Launched cooperatively: the runtime guarantees that the grid is resident as a whole (the blocks wait for each other), and
+  //      one alignment per device at a time takes this route. ----
+  bool persist_lock = false;
+  const bool want_persist = h->persist && !finished && h->persist_slots > 0 && pass_impl() == 0 && !c.pa.fused && !xcd_order && !stamp_path && !span_path && !qstat_path &&
+                            !c.sa.dbg_stamps && max_passes + 1 <= kMaxPersistPasses;
+  if (want_persist) persist_lock = persist_mutex(h->device).try_lock();
+  if (persist_lock) {
+    struct Unlock {
+      std::mutex& m;
+      ~Unlock() { m.unlock(); }
+    } unlock{persist_mutex(h->device)};
+    int* const ctl = h->order_flag.as<int>();
+    const int sel = h->order_sel;
+    // {flag 0, ticket, gen, flag 1}: ticket and gen start at zero, and so does the flag of the buffer this alignment's solver will fill
+    HIP_TRY(hipMemsetAsync(ctl + (sel == 0 ? 1 : 0), 0, 3 * sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(h->gen_lines.p, 0, (size_t)kGenLines * kGenStride * sizeof(int), h->stream));
+    PassArgs pa = c.pa;
+    pa.fused = 1;
+    pa.persist = 1;
+    pa.max_passes = (int)max_passes;
+    pa.sa = c.sa;
+    pa.sa.persist = 1;
+    pa.sa.grp_order = sel == 0 ? h->grp_order_alt.as<int>() : h->grp_order.as<int>();
+    pa.sa.order_valid = sel == 0 ? ctl + 3 : ctl;
+    pa.sa.pass_ticks = (h->profiling && max_passes <= kMaxTickPasses) ? h->pin_ticks : nullptr;
+    const int grid = std::min(c.nblocks, h->persist_slots);
+    void* kargs[] = {&pa};
+    static const bool coop = !(std::getenv("NGICP_PERSIST_COOP") && std::atoi(std::getenv("NGICP_PERSIST_COOP")) == 0);
+    bool launched_ok = true;
+    if (coop) {
+      const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_gicp_persist<2, 3>), dim3((unsigned)grid), dim3(256), kargs, 0, h->stream);
+      if (le != hipSuccess) {  // (e.g. the runtime finds the grid too large to be resident: one launch per pass then)
+        (void)hipGetLastError();
+        launched_ok = false;
+      }
+    } else {  // (A/B timing only: an ordinary launch relies on nothing else running on the device)
+      hipLaunchKernelGGL((k_gicp_persist<2, 3>), dim3((unsigned)grid), dim3(256), 0, h->stream, pa);
+    }
+    bool ok = false;
+    while (launched_ok) {
+      const int prog = __atomic_load_n(h->h_progress, __ATOMIC_ACQUIRE);
+      if (prog & kProgressDone) {
+        ok = true;
+        break;
+      }
+      if ((++spins & 0x3fff) == 0) {
+        if (hipStreamQuery(h->stream) == hipSuccess) {  // the kernel has left: done flag (then it is in memory by now), or its blocks gave up waiting
+          ok = (__atomic_load_n(h->h_progress, __ATOMIC_ACQUIRE) & kProgressDone) != 0;
+          break;
+        }
+        if (now_ms() - t_loop > 30000.0) throw ArgError{NGICP_ERR_HIP, "the registration loop did not finish within 30 s"};
+      }
+      if (h->host_wait) sched_yield(); else __builtin_ia32_pause();
+    }
+    if (ok) {
+      finished = true;
+      st.hot = *h->pin_final;
+      persist_loop_ms = (float)((double)(st.hot.t_done - st.hot.t_first) * 1e-5);
+      persist_done = true;
+      if (st.hot.passes >= 3 && c.nblocks <= kMaxOrderGroups) h->order_sel = sel ^ 1;  // the solver of the third pass left a fresh order in the other buffer
+    } else {
+      // (never seen: the blocks' bounded wait ran out - e.g. the grid was not resident as a whole.  The state goes back to the guess and the
+      // alignment takes one launch per pass.)
+      std::fprintf(stderr, launched_ok ? "ngicp: the persistent registration kernel gave up waiting; falling back to one launch per pass\n"
+                                       : "ngicp: the persistent registration kernel could not be launched; falling back to one launch per pass\n");
+      h->persist = 0;
+      HIP_TRY(hipMemsetAsync(h->order_flag.p, 0, 4 * sizeof(int), h->stream));
+      HIP_TRY(hipMemcpyAsync(h->state.p, &h->pin_state[0], sizeof(st), hipMemcpyHostToDevice, h->stream));
+      *h->h_progress = 0;
+    }
+  }
   while (!finished && launched < max_passes) {
     const int prog = *reinterpret_cast<volatile int*>(h->h_progress);
     if (prog & kProgressDone) break;
@@ -990,12 +1101,30 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       continue;
     }
     const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
+    static const bool persist_one = std::getenv("NGICP_PERSIST_ONE") != nullptr;  // A/B only: the persistent kernel's code, one launch per pass
+    if (persist_one && h->persist_slots > 0 && max_passes + 1 <= kMaxPersistPasses) {
+      PassArgs pa = c.pa;
+      pa.fused = 1;
+      pa.persist = std::atoi(std::getenv("NGICP_PERSIST_ONE")) == 2 ? 2 : 1;
+      pa.first_pass = (int)launched;
+      pa.max_passes = 1;
+      pa.sa = c.sa;
+      pa.sa.persist = 1;
+      HIP_TRY(hipMemsetAsync(pa.ticket, 0, sizeof(int), h->stream));
+      HIP_TRY(hipMemsetAsync(h->gen_lines.p, 0, (size_t)kGenLines * kGenStride * sizeof(int), h->stream));
+      hipExtLaunchKernelGGL((k_gicp_persist<2, 3>), dim3((unsigned)std::min(c.nblocks, h->persist_slots)), dim3(256), 0, h->stream,
+                            timed ? h->prof_events[2 * launched] : nullptr, timed ? h->prof_events[2 * launched + 1] : nullptr, 0, pa);
+      ++launched;
+      continue;
+    }
     launch_pass(h, c.pa, c.nblocks, h->stream, timed ? h->prof_events[2 * launched] : nullptr, timed ? h->prof_events[2 * launched + 1] : nullptr);
     if (!c.pa.fused) hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(kSolveThreads), 0, h->stream, c.sa);
     ++launched;
   }
   float loop_ms = 0.f;
-  if (finished) {
+  if (persist_done) {
+    loop_ms = persist_loop_ms;
+  } else if (finished) {
     HIP_TRY(hipStreamSynchronize(h->stream));  // (max_iterations <= 0: nothing was launched; the state is the initial one)
   } else {
     // The solver writes the final state image into pinned memory and THEN raises the done flag (system-scope release): no copy,
@@ -1078,7 +1207,30 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
   s.staged_fraction = st.hot.passes > 0 ? st.hot.staged_total / ((double)st.hot.passes * (double)h->src.dev->n) : 0.0;
   if (st.hot.passes > 1) h->prev_staged_fraction = s.staged_fraction;
   s.pass_ms_total = 0.0;
-  if (h->profiling) {
+  if (h->profiling && persist_done) {
+    // the persistent kernel's own stamps (100 MHz): a pass lasts from its release (the first: the alignment's first stamp) to the arrival
+    // of its last block; the optimiser's step and the release that follows are not part of it
+    const long timed = std::min<long>(st.hot.passes, kMaxTickPasses);
+    int counted = 0;
+    if ((long)h->p.max_iter * std::max(1, h->p.lm_max_iter) + 1 <= kMaxTickPasses) {
+      for (long i = 0; i < timed; ++i) {
+        const unsigned long long from = i == 0 ? st.hot.t_first : h->pin_ticks[2 * (i - 1) + 1], to = h->pin_ticks[2 * i];
+        if (to > from) {
+          s.pass_ms_total += (double)(to - from) * 1e-5;
+          ++counted;
+        }
+      }
+    }
+    s.passes_timed = counted;
+    if (std::getenv("NGICP_DEBUG_TICKS")) {  // diagnostic only: every pass and every step of the alignment, in microseconds
+      std::fprintf(stderr, "persistent kernel, pass / step us:");
+      for (long i = 0; i < timed; ++i) {
+        const unsigned long long from = i == 0 ? st.hot.t_first : h->pin_ticks[2 * (i - 1) + 1];
+        std::fprintf(stderr, " %.1f/%.1f", (double)(h->pin_ticks[2 * i] - from) * 1e-2, (double)(h->pin_ticks[2 * i + 1] - h->pin_ticks[2 * i]) * 1e-2);
+      }
+      std::fprintf(stderr, "\n");
+    }
+  } else if (h->profiling) {
     // HIP events on the handle's own stream around every pass launch that did work
     const long timed = std::min<long>(st.hot.passes, (long)h->prof_events.size() / 2);
     int counted = 0;
@@ -1199,7 +1351,13 @@ int ngicp_create(int device, ngicp_t** out) {
       HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
       HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gicp_pass<2, 3>, 256, 0));
       h->pass_slots = std::max(1, cus) * std::max(1, per_cu);
+      int per_cu_p = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_gicp_persist<2, 3>, 256, 0) == hipSuccess) h->persist_slots = std::max(0, cus) * std::max(0, per_cu_p);
+      int coop = 0;
+      if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) h->persist_slots = 0;
     }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_ticks), 2 * kMaxTickPasses * sizeof(unsigned long long), hipHostMallocDefault));
+    if (const char* s = std::getenv("NGICP_PERSIST")) h->persist = std::atoi(s);
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_CHUNK")) h->chunk_pairs = std::max(1, std::min(64, std::atoi(s)));
@@ -1238,6 +1396,7 @@ int ngicp_destroy(ngicp_t* h) {
     if (e) (void)hipEventDestroy(e);
   if (h->pin_state) (void)hipHostFree(h->pin_state);
   if (h->pin_final) (void)hipHostFree(h->pin_final);
+  if (h->pin_ticks) (void)hipHostFree(h->pin_ticks);
   if (h->h_progress) (void)hipHostFree(h->h_progress);
   if (h->h_shard_done) (void)hipHostFree(h->h_shard_done);
   for (auto& e : h->ev_shard)

@@ -69,10 +69,28 @@ struct LmHot {
   double final_H[36];  // H of the last accepted step, row-major (final_hessian_, impl/lsq_registration_impl.hpp:155,203); identity until then
   unsigned long long t_first, t_done;  // 100 MHz counter at the start of the alignment's first pass / when the solver set `done`
 };
+// What a pass needs of the state, as 64 dwords (256 bytes, two cache lines of their own).  The persistent kernel reads the view of pass p
+// from entry p of a RING of views that begins at LmState::view and continues behind the state (the solver that ends pass p - 1 stores
+// it write-through): an address no CU and no L2 of this launch has touched before cannot be stale anywhere, so the blocks read it
+// with plain scalar loads, exactly as a launch-per-pass kernel reads the state - and the compiler may reload the values instead of
+// keeping 40 registers alive through the search.
+constexpr int kViewXi = 0;     // [24] the trial pose xi: R (9 doubles), t (3 doubles)
+constexpr int kViewXiF = 24;   // [12] float(xi), rows of [R|t]
+constexpr int kViewDone = 36, kViewCur = 37, kViewHaveLin = 38;
 struct LmState {
   LmHot hot;
   float xi_f[12];  // float(xi): rows of [R|t], the matrix used for the NN query (impl/nano_gicp_impl.hpp:178)
+  // entry 0 of the persistent kernel's ring of per-pass views (kView*); entries 1 .. max_passes follow at a stride of kViewWords.
+  // Every entry lies in cache lines of its own (L2: 128 bytes, scalar cache: 64) with an unused gap behind it: reading entry p must
+  // not bring any byte of entry p + 1 into a cache before the solver has written it.
+  alignas(512) int view[128];
 };
+constexpr int kViewWords = 128;
+// The release word of the persistent kernel exists kGenLines times, 128 bytes apart; block b waits on copy b % kGenLines.  (With ONE
+// word, the ~770 waiting blocks' agent-scope polls - every one goes out to memory - queued on a single channel: whatever else mapped
+// to that channel waited behind them, and the blocks still working took 2.5x as long.)
+constexpr int kGenLines = 256, kGenStride = 32;
+static_assert(sizeof(LmState) % 512 == 0 && offsetof(LmState, view) % 512 == 0, "ring entries are 512-byte aligned");
 
 struct alignas(4) Xyz { float x, y, z; };
 __device__ __forceinline__ float sqdist(float qx, float qy, float qz, const Xyz& p) {
@@ -116,6 +134,9 @@ struct SolveArgs {
   LmHot* final_host;       // pinned host memory, or null: the state image, written when the alignment is done, BEFORE the done flag goes out
   int* order_valid;        // device word: the solver has published a group order (heaviest first) for the next pass
   const unsigned long long* t_first;  // device word the first pass of an alignment stamps (100 MHz counter)
+  int persist;             // the solver runs between two passes of ONE launch: every word other blocks (on other XCDs) wrote or will read
+                           // goes through agent-scope loads / write-through stores, and the launch order it builds is for the NEXT alignment
+  unsigned long long* pass_ticks;  // persist: [2 * max passes] 100 MHz ticks {last block arrived, next pass released} per pass, or null
 };
 
 struct PassArgs {
@@ -153,7 +174,14 @@ struct PassArgs {
   const int* order_valid;          // device word: grp_order holds a complete order
   unsigned long long* t_first;     // device word: stamped by the first pass of an alignment (block 0), or null
   int fused;
-  int* ticket;   // zero before the launch; the last block puts it back
+  int* ticket;   // zero before the launch; the last block puts it back (persistent: counts on, pass after pass)
+  // persistent: ONE launch per alignment.  A block keeps its groups for the whole alignment (their correspondences and Mahalanobis
+  // matrices never leave its CU's L1 / its XCD's L2: no kernel boundary drops them), the blocks meet at the ticket after every pass,
+  // the last one to arrive steps the optimiser and releases the next pass through `gen`.
+  int persist;
+  int first_pass;  // (0 unless the kernel is launched once per pass for an A/B measurement: the ring entry the launch begins with)
+  int max_passes;
+  int* gen;      // zero before the launch: passes released so far (agent scope), kGenLines copies in cache lines of their own
   SolveArgs sa;
 };
 
@@ -618,8 +646,12 @@ struct SolveShared {
 // The body of the solver for a block of THREADS threads (512: k_lm_solve; 256: the last block of a fused pass).  AGENT: the group rows
 // and costs were written by other blocks of the SAME launch (write-through stores, published by a ticket; the caller has run the
 // agent-scope acquire): they are then read with agent-scope loads, which bypass this CU's L1 whatever it holds.
-template <int THREADS, bool AGENT>
+// PERSIST: the solver between two passes of the persistent kernel.  There is no kernel boundary and no fence anywhere: every word another
+// block wrote (group rows, costs - and the state image, which the solver of the previous pass, possibly on another XCD, stored) is read
+// with agent-scope loads, the state image and the pass's view of it are stored write-through.
+template <int THREADS, bool AGENT, bool PERSIST = false>
 __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<THREADS>& sh) {
+  static_assert(!PERSIST || AGENT, "the persistent solver is an agent-scope one");
   constexpr int kSolveThreads = THREADS;
   constexpr int kSolveSubs = 32;                      // subsets of rows (row g belongs to subset g mod 32), whatever the block size
   constexpr int kThreadSubs = THREADS / 16;           // subsets the block's threads cover at once
@@ -640,7 +672,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   do {                                                                               \
     if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
-  const int done_at_entry = st->hot.done;
+  const int done_at_entry = PERSIST ? 0 : st->hot.done;  // (persistent: the blocks left the pass loop when they saw the flag)
   if (a.dbg_stamps && threadIdx.x == 0 && !done_at_entry) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
   // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
   //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
@@ -657,12 +689,16 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   constexpr int kCostPerThread = kMaxOrderGroups / kSolveThreads;
   // (the fused block has three sorting waves instead of seven: the order is refreshed after the first three passes of an alignment -
   // the costs settle with the warm start - and after every fourth from then on, so that it stays off the serial lane's path)
-  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups && (!AGENT || st->hot.passes < 3 || (st->hot.passes & 3) == 3);
+  // (persistent: the blocks keep their groups for the whole alignment; the order built from the costs of the third pass - warm starts in
+  // place - goes to the buffer the NEXT alignment launches with)
+  const int passes_at_entry = PERSIST ? __hip_atomic_load(&st->hot.passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : st->hot.passes;
+  const bool order_it = a.mode == 0 && a.grp_order && a.nblocks <= kMaxOrderGroups && (PERSIST ? passes_at_entry == 2 : (!AGENT || passes_at_entry < 3 || (passes_at_entry & 3) == 3));
   int hv[kHotPerThread];
 #pragma unroll
   for (int k = 0; k < kHotPerThread; ++k) {
     const int w = threadIdx.x + k * kSolveThreads;
-    hv[k] = w < kHotWords ? reinterpret_cast<const int*>(&st->hot)[w] : 0;
+    if constexpr (PERSIST) hv[k] = w < kHotWords ? __hip_atomic_load(reinterpret_cast<const int*>(&st->hot) + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    else hv[k] = w < kHotWords ? reinterpret_cast<const int*>(&st->hot)[w] : 0;
   }
   // (One CU moves 64 B per clock: the 222 KB of 866 rows are ~3.5k cycles on top of the latency.  Rows beyond the grid are skipped by
   // a branch each: fetching a stand-in row instead - branch-free issue - measured slower, the stand-ins pile up on one channel.)
@@ -670,7 +706,15 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   // (AGENT: the caller's agent-scope acquire has dropped this CU's L1, the producers stored write-through and no line of these rows
   // can be in this XCD's L2 from before - nobody read them earlier in this launch: plain 16-byte loads, as MI355X_MICROARCH.md's
   // "valid forms" prescribe for the consumer side)
-  auto load_row = [](const double2* q) -> double2 { return *q; };
+  // (PERSIST: this XCD's L2 may hold the rows of an earlier pass - one of its blocks was the solver then - so the loads say agent scope)
+  auto load_row = [](const double2* q) -> double2 {
+    if constexpr (PERSIST) {
+      const double* d = reinterpret_cast<const double*>(q);
+      return make_double2(__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    } else {
+      return *q;
+    }
+  };
   // (The order of the sums never depends on the block size: 32 subsets of rows; a thread of a 256-thread block takes two of them.)
   double2 p[kPer * kSolveChunk];
 #pragma unroll
@@ -684,7 +728,8 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
 #pragma unroll
   for (int k = 0; k < kCostPerThread; ++k) {
     const int gi = threadIdx.x + k * kSolveThreads;
-    oc[k] = (order_it && gi <= last_row) ? a.grp_cost[gi] : 0;
+    if constexpr (PERSIST) oc[k] = (order_it && gi <= last_row) ? __hip_atomic_load(a.grp_cost + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    else oc[k] = (order_it && gi <= last_row) ? a.grp_cost[gi] : 0;
   }
   if (a.mode == 0 && done_at_entry) return;  // (a scalar load issued at the top: it does not wait for the vector loads above)
   // The serial lane works on the LDS image of the state in place (a register-resident copy needs ~260 VGPRs: it spills at two
@@ -877,8 +922,12 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) st->xi_f[r * 4 + c] = (float)L.xi.R[r * 3 + c];
-          st->xi_f[r * 4 + 3] = (float)L.xi.t[r];
+          for (int c = 0; c < 4; ++c) {
+            const float f = (float)(c < 3 ? L.xi.R[r * 3 + c] : L.xi.t[r]);
+            // (persistent: solvers of different passes sit on different XCDs - a plain store would leave one dirty copy of the word per L2)
+            if constexpr (PERSIST) __hip_atomic_store(&st->xi_f[r * 4 + c], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else st->xi_f[r * 4 + c] = f;
+          }
         }
       }
     }
@@ -886,7 +935,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   // wave 0 stores the state image back (lane 0's LDS writes are ordered before the other lanes' reads by the fence pair)
   if (a.mode == 0 && lane == 0 && L.done) {
     L.t_done = __builtin_amdgcn_s_memrealtime();
-    if (a.t_first) L.t_first = *a.t_first;
+    if (a.t_first) L.t_first = PERSIST ? __hip_atomic_load(a.t_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *a.t_first;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -904,7 +953,27 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   // progress for the host (it keeps a few (pass, solve) pairs in flight and stops feeding the stream when it sees the flag)
   if (a.mode == 0 && a.progress_host && lane == 0)
     __hip_atomic_store(a.progress_host, (L.passes & kProgressMask) | (L.done ? kProgressDone : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (ordered behind the image by the fence above when done)
-  for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
+  if constexpr (PERSIST) {
+    for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64)
+      __hip_atomic_store(reinterpret_cast<int*>(&st->hot) + w, reinterpret_cast<const int*>(&L)[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the next pass's view of the state (LmState::view)
+    int v = 0;
+    if (lane < 24) {
+      v = reinterpret_cast<const int*>(&L.xi)[lane];
+    } else if (lane < 36) {
+      const int r = (lane - 24) >> 2, cI = (lane - 24) & 3;
+      v = __float_as_int((float)(cI < 3 ? L.xi.R[r * 3 + cI] : L.xi.t[r]));
+    } else if (lane == kViewDone) {
+      v = L.done;
+    } else if (lane == kViewCur) {
+      v = L.cur;
+    } else if (lane == kViewHaveLin) {
+      v = L.have_lin;
+    }
+    __hip_atomic_store(st->view + (size_t)L.passes * kViewWords + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (pass L.passes comes next)
+  } else {
+    for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
+  }
   NG_SSTAMP(6);
 #undef NG_SSTAMP
 }
@@ -977,502 +1046,9 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
   if (a.dbg_span && threadIdx.x == 0) a.dbg_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();  // (the 100 MHz counter: the same on every CU)
   if (a.t_first && blockIdx.x == 0 && threadIdx.x == 0 && !st->hot.have_lin) *a.t_first = __builtin_amdgcn_s_memrealtime();
-  for (int item = group * 4 + wave; item < a.n_batches; item = a.n_batches) {
-    const int2 it = a.batches[item];
-    const int qbase = it.x, qcount = it.y, batch = item;
-    float mybest = 3.4028234664e38f;
-    int mypos = -1;
-    const int i = qbase + lane;
-    const bool mine = lane < qcount;
-    NG_STAMP(1);
-    // ---- the operands of this lane's own query (lane l <-> query qbase + l: the tail's mapping), ONE round trip: the source point,
-    //      the previous correspondence with its target point, the previous Mahalanobis matrix.  K4 is evaluated at once (it needs
-    //      nothing else), so that nothing but the source point and one double stays in registers across the search; the search takes
-    //      its query and its warm start from the same loads by shuffles ----
-    const bool have_prev = st->hot.have_lin != 0;
-    float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);
-    int j_old = -1;
-    float4 bp_old = make_float4(0.f, 0.f, 0.f, 0.f);
-    double k4 = 0.0;
-    if (mine) {
-      double Mold[6] = {0, 0, 0, 0, 0, 0};
-      sp = a.qpts[i];
-      if (have_prev) {  // K4's correspondence and the search's warm start
-        bp_old = tpt_old[i];
-        j_old = __float_as_int(bp_old.w);
-      }
-      if (do_err) {
-        const double* M = mahal_old + (size_t)i * 6;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) Mold[e] = M[e];
-      }
-      // K4: error of the trial pose under the previous correspondences (impl/nano_gicp_impl.hpp:273-296)
-      if (do_err && j_old >= 0) {
-        const double ax = (double)sp.x, ay = (double)sp.y, az = (double)sp.z;
-        const double tax = R[0] * ax + R[1] * ay + R[2] * az + t[0];  // T * a in FP64 (impl/nano_gicp_impl.hpp:289)
-        const double tay = R[3] * ax + R[4] * ay + R[5] * az + t[1];
-        const double taz = R[6] * ax + R[7] * ay + R[8] * az + t[2];
-        const double ex = (double)bp_old.x - tax, ey = (double)bp_old.y - tay, ez = (double)bp_old.z - taz;
-        const double m00 = Mold[0], m01 = Mold[1], m02 = Mold[2], m11 = Mold[3], m12 = Mold[4], m22 = Mold[5];
-        const double mex = m00 * ex + m01 * ey + m02 * ez;
-        const double mey = m01 * ex + m11 * ey + m12 * ez;
-        const double mez = m02 * ex + m12 * ey + m22 * ez;
-        k4 = ex * mex + ey * mey + ez * mez;
-      }
-    }
-
-    if (do_lin && (a.mode & 8)) {  // DEBUG timing build: fake search result
-      mypos = (qbase + lane) % 1000;
-      mybest = 0.01f;
-    } else if (do_lin) {
-      // ---- K2 (impl/nano_gicp_impl.hpp:178,190-192): the query of this lane pair, handed over by the lane that loaded it ----
-      const int qi = qbase + grp;
-      const bool qok = grp < qcount;
-      const float qpx = __shfl(sp.x, grp), qpy = __shfl(sp.y, grp), qpz = __shfl(sp.z, grp);
-      const int jp = __shfl(j_old, grp);
-      float4 bpo;
-      bpo.x = __shfl(bp_old.x, grp); bpo.y = __shfl(bp_old.y, grp); bpo.z = __shfl(bp_old.z, grp); bpo.w = 0.f;
-      float qx = 0.f, qy = 0.f, qz = 0.f;
-      int cx = 0, cy = 0, cz = 0;
-      if (qok) {
-        // Eigen 4x4 * 4-vector in float: ((c0*x + c1*y) + c2*z) + c3*1
-        qx = ((Tf[0] * qpx + Tf[1] * qpy) + Tf[2] * qpz) + Tf[3];
-        qy = ((Tf[4] * qpx + Tf[5] * qpy) + Tf[6] * qpz) + Tf[7];
-        qz = ((Tf[8] * qpx + Tf[9] * qpy) + Tf[10] * qpz) + Tf[11];
-        cell_coords(g, qx, qy, qz, cx, cy, cz);
-      }
-      float best = 3.4028234664e38f;
-      int pos = -1;
-      // Warm start: between two LM trials the pose moves little, so the previous correspondence is almost always still the
-      // nearest neighbour.  It is a genuine target point, so taking it as the first candidate keeps the search exact (the
-      // total order decides as before) - but every row and every window is pruned against a tight bound from the start.
-      if (qok && jp >= 0) {
-        best = sqdist(qx, qy, qz, bpo);
-        pos = jp;
-      }
-      NG_STAMP(2);
-      // ---- rows beyond ring 1 are served from a LIST of the non-empty rows of the batch's region; only batches that looked
-      //      beyond ring 1 in the previous pass pay for it.  The region's bounding box comes from
-      //      the batch's precomputed AABB pushed through the trial pose; a batch never leaves one Morton tile. ----
-      int Y0 = 0, Z0 = 0, wy = 1, grow = 0, nlive = 0;
-      int b0x = 0, b0y = 0, b0z = 0, b1x = 0, b1y = 0, b1z = 0;
-      bool listed = false;
-      // (The first pass of an alignment has no flags yet: it lists for every batch or for none, as the host decides - mode bit 5.)
-      if (a.stage_grow >= 2 && (have_prev ? a.batch_far[batch] != 0 : (a.mode & 32) != 0)) {  // wave-uniform
-        {
-          const float* bb = a.batch_boxes + (size_t)batch * 6;
-          const float bcx = bb[0], bcy = bb[1], bcz = bb[2], bhx = bb[3], bhy = bb[4], bhz = bb[5];
-          const float mx = ((Tf[0] * bcx + Tf[1] * bcy) + Tf[2] * bcz) + Tf[3];
-          const float my = ((Tf[4] * bcx + Tf[5] * bcy) + Tf[6] * bcz) + Tf[7];
-          const float mz = ((Tf[8] * bcx + Tf[9] * bcy) + Tf[10] * bcz) + Tf[11];
-          const float pad = 1e-3f * g.h;
-          const float ex = (fabsf(Tf[0]) * bhx + fabsf(Tf[1]) * bhy) + fabsf(Tf[2]) * bhz + pad + 4e-6f * (fabsf(mx) + bhx + bhy + bhz);
-          const float ey = (fabsf(Tf[4]) * bhx + fabsf(Tf[5]) * bhy) + fabsf(Tf[6]) * bhz + pad + 4e-6f * (fabsf(my) + bhx + bhy + bhz);
-          const float ez = (fabsf(Tf[8]) * bhx + fabsf(Tf[9]) * bhy) + fabsf(Tf[10]) * bhz + pad + 4e-6f * (fabsf(mz) + bhx + bhy + bhz);
-          cell_coords(g, mx - ex, my - ey, mz - ez, b0x, b0y, b0z);
-          cell_coords(g, mx + ex, my + ey, mz + ez, b1x, b1y, b1z);
-        }
-        int rows, X0 = 0, XS = 1;
-        for (grow = a.stage_grow;; --grow) {  // largest grow whose region fits the row tables (no memory traffic)
-          X0 = max(b0x - grow, 0);
-          Y0 = max(b0y - grow, 0);
-          Z0 = max(b0z - grow, 0);
-          const int X1 = min(b1x + grow, g.nx - 1), Y1 = min(b1y + grow, g.ny - 1), Z1 = min(b1z + grow, g.nz - 1);
-          XS = X1 - X0 + 1;
-          wy = Y1 - Y0 + 1;
-          rows = wy * (Z1 - Z0 + 1);
-          if ((rows <= kStageRows && XS <= kStageXs) || grow == 2) break;
-        }
-        if (rows <= kStageRows && XS <= kStageXs) {
-          // lane owns region rows lane, lane + 64, ...: bounds of their runs in the cell-sorted target, and the
-          // row's ring distance from the batch box (rows are listed nearest ring first)
-          int rs[kStageRowsPerLane], rn[kStageRowsPerLane], rho[kStageRowsPerLane], ryz[kStageRowsPerLane], rk[kStageRowsPerLane];
-#pragma unroll
-          for (int k = 0; k < kStageRowsPerLane; ++k) {
-            const int r = lane + 64 * k;
-            const bool has = r < rows;
-            const int ry = Y0 + r % wy, rz = Z0 + r / wy;
-            const int rb = has ? (rz * g.ny + ry) * g.nx + X0 : 0;
-            const int sv = has ? a.tgt_cell_start[rb] : 0, ev = has ? a.tgt_cell_start[rb + XS] : 0;
-            // where the batch box's own x-cells begin / end inside the row (same cache lines): a walk of the row starts between them
-            const int ka = has ? a.tgt_cell_start[rb + (b0x - X0)] : 0, kb = has ? a.tgt_cell_start[rb + (b1x + 1 - X0)] : 0;
-            rs[k] = sv;
-            rn[k] = ev - sv;
-            rk[k] = min(ka - sv, 0xffff) | (min(kb - sv, 0xffff) << 16);
-            rho[k] = max(max(b0y - ry, ry - b1y), max(max(b0z - rz, rz - b1z), 0));
-            ryz[k] = ry | (rz << 16);
-          }
-          wave_lds_sync();  // the previous batch's readers are done with the tables (and with the reduction scratch)
-          // ring by ring: the non-empty rows, nearest ring first
-          for (int lev = 0; lev <= grow; ++lev) {
-#pragma unroll
-            for (int k = 0; k < kStageRowsPerLane; ++k) {
-              const bool on = rn[k] > 0 && rho[k] == lev;
-              const unsigned long long m = __ballot(on);
-              if (on) S.live[nlive + __popcll(m & ((1ull << lane) - 1ull))] = make_int4(ryz[k], rn[k], rs[k], rk[k]);  // {y | z << 16, points, first point, box x-range inside the row}
-              nlive += __popcll(m);
-            }
-          }
-          listed = true;
-        }
-      }
-      NG_STAMP(3);
-      if (a.dbg_stamps && lane == 0) {
-        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
-        d[10] = (unsigned long long)(listed ? grow : 0);
-        d[11] = (unsigned long long)nlive;
-        d[12] = (unsigned long long)qcount;
-        d[13] = (unsigned long long)((b1x - b0x + 1) | ((b1y - b0y + 1) << 8) | ((b1z - b0z + 1) << 16));
-      }
-      bool went_far = false;
-      // the AABB transform is conservative, but guard against rounding: a query whose cell is outside the box
-      // simply takes the unlisted path beyond ring 1
-      const bool in_box = qok && listed && cx >= b0x && cx <= b1x && cy >= b0y && cy <= b1y && cz >= b0z && cz <= b1z;
-      unsigned int dbg_g1 = 0, dbg_g2 = 0;
-      auto pack_key = [](float d, int p) { return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)p; };
-      // ---- rings 0..1.  The 3 x 3 window of (y,z) rows around the query's cell; a row of it is the x-sorted run of the cells
-      //      cx-1..cx+1.  The lane pair of a query fetches, in ONE round trip, the four cell bounds around cx of every row that
-      //      the (y,z)-gap test does not rule out (one 16-byte load per row: the cell-start table is padded for it).  Every
-      //      non-empty row becomes a UNIT {query, run, starting position} in an LDS queue; whichever lane is free pops the next
-      //      unit and walks it.  The walk starts at the previous correspondence when that lies in the run (the window is then
-      //      centred on the best candidate), else where qx sits inside its own cell (interpolated). ----
-      if (qok && sub == 0) {
-        if (in_box) ++nstaged;
-        S.qtab[grp] = make_float4(qx, qy, qz, 0.f);
-        S.qkey[grp] = pack_key(best, pos);  // the warm start, or (FLT_MAX, -1)
-      }
-      if (lane == 0) S.q_tail = 0, S.q_head = 0;
-      if (a.dbg_qstats && lane < 32) S.qstat[lane][0] = S.qstat[lane][1] = S.qstat[lane][2] = 0;
-      wave_lds_sync();
-      if (qok) {
-        const float lim = fminf(best, a.gate_sq_f);
-        constexpr int kRowsPerLane = (9 + G - 1) / G;
-        struct alignas(4) Bounds4 { int v[4]; };
-        Bounds4 bnd[kRowsPerLane];
-        float gap[kRowsPerLane];
-        int code[kRowsPerLane];
-#pragma unroll
-        for (int k = 0; k < kRowsPerLane; ++k) {
-          const int order = sub + k * G;  // nearest rows first: the own row, its 4 edge neighbours, the 4 corners
-          const int tt = order == 0 ? 4 : (order < 5 ? 2 * order - 1 : (order == 5 ? 0 : (order == 6 ? 2 : (order == 7 ? 6 : 8))));
-          const int z = cz + tt / 3 - 1, y = cy + tt % 3 - 1;
-          code[k] = -1;
-          gap[k] = 0.f;
-          bnd[k] = Bounds4{{0, 0, 0, 0}};
-          if (order < 9 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-            gap[k] = row_gap_sq(g, y, z, cy, cz, qy, qz);
-            if (gap[k] <= lim) {
-              code[k] = tt;
-              bnd[k] = *reinterpret_cast<const Bounds4*>(a.tgt_cell_start + ((z * g.ny + y) * g.nx + cx - 1));  // starts of cells cx-1, cx, cx+1, cx+2
-            }
-          }
-        }
-        const float fx = fminf(fmaxf((qx - (g.ox + (float)cx * g.h)) * g.inv_h, 0.f), 1.f);
-        // (queue slots from ballots: up to 64 lanes adding 1 to the same LDS word at once was nearly every LDS-busy cycle of the
-        // kernel a conflict cycle - profiles/r02_c3_pass_counters.json: SQ_LDS_BANK_CONFLICT 0.97 M of SQ_ACTIVE_INST_LDS 1.06 M)
-        int ntail = 0;
-#pragma unroll
-        for (int k = 0; k < kRowsPerLane; ++k) {
-          const int s0 = cx > 0 ? bnd[k].v[0] : bnd[k].v[1], e0 = cx < g.nx - 1 ? bnd[k].v[3] : bnd[k].v[2];
-          const bool has = code[k] >= 0 && e0 > s0;
-          const unsigned long long hm = __ballot(has);
-          if (has) {
-            const int m = (jp >= s0 && jp < e0) ? jp : bnd[k].v[1] + (int)(fx * (float)(bnd[k].v[2] - bnd[k].v[1]));
-            const int slot = ntail + __popcll(hm & ((1ull << lane) - 1ull));  // at most 32 x 9 units: fits
-            S.unit_q[slot] = grp | (code[k] << 5) | (min(max(m - s0, 0), (1 << 22) - 1) << 9);
-            S.unit_s[slot] = s0;
-            S.unit_e[slot] = e0;
-            S.unit_g[slot] = gap[k];
-          }
-          ntail += __popcll(hm);
-        }
-        if (lane == 0) S.q_tail = ntail, S.q_head = 64 / kWalkLanes;  // (lane 0 holds a query whenever the batch has one)
-      }
-      wave_lds_sync();
-      NG_STAMP(16);
-      {
-        const int tail = S.q_tail;
-        unsigned int popped = 0;
-        // the first 64 units go to the lanes (the first 16 to the quads) by number; only what is left beyond them is popped from
-        // the shared counter
-        constexpr int kWalkers = 64 / kWalkLanes;
-        const int ql = lane % kWalkLanes;
-        auto next_unit = [&]() {
-          if (tail <= kWalkers) return tail;
-          if constexpr (kWalkLanes == 1) {
-            return atomicAdd(&S.q_head, 1);
-          } else {
-            int nu = 0;
-            if (ql == 0) nu = atomicAdd(&S.q_head, 1);
-            return quad_perm_i<0x00>(nu);
-          }
-        };
-        for (int u = lane / kWalkLanes; u < tail; u = next_unit()) {
-          ++popped;
-          const int uq = S.unit_q[u], qs = uq & 31, s0 = S.unit_s[u], e0 = S.unit_e[u];
-          const float gyz = S.unit_g[u];
-          const float4 q = S.qtab[qs];
-          const unsigned long long k0 = S.qkey[qs];  // whatever the query's other units have found by now
-          float ub = __uint_as_float((unsigned int)(k0 >> 32));
-          int up = (int)(unsigned int)k0;
-          if (gyz > fminf(ub, a.gate_sq_f)) continue;
-          const unsigned int c_before = ncand;
-          const unsigned int steps_before1 = dbg_g1;
-          if constexpr (kWalkLanes == 1) scan_global_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1);
-          else scan_quad_outward<kWin, kSideStep>(a.tgt3, s0, e0, s0 + (uq >> 9), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g1, ql);
-          if (ql == 0) {
-            if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + min((int)((dbg_g1 - steps_before1) & 0xffff), 63), 1);  // diagnostic: window steps per ring-1 unit
-            atomicMin(&S.qkey[qs], pack_key(ub, up));
-            if (a.dbg_qstats) {
-              atomicAdd(&S.qstat[qs][0], (int)(ncand - c_before));
-              atomicAdd(&S.qstat[qs][1], 1);
-            }
-          }
-        }
-        NG_STAMP(17);
-        if (a.dbg_stamps) {
-          unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
-          atomicMax(&d[18], (unsigned long long)popped);
-          if (lane == 0) d[19] = (unsigned long long)tail;
-        }
-      }
-      wave_lds_sync();
-      if (qok) {
-        const unsigned long long k1 = S.qkey[grp];
-        best = __uint_as_float((unsigned int)(k1 >> 32));
-        pos = (int)(unsigned int)k1;
-      }
-      NG_STAMP(4);
-      float bound1 = 0.f;
-      if (qok) {
-        bound1 = unexplored_bound_sq(g, qx, qy, qz, cx, cy, cz, 1);
-        went_far = !(best <= bound1 || bound1 >= a.gate_sq_f);
-      }
-      const unsigned int dbg_c1 = ncand;
-      unsigned int dbg_rows = 0;
-      // ---- rings 2..grow: units for the listed rows (nearest ring first) that can still hold a closer point, in rounds of
-      //      kUnitCap; between rounds every query picks up what its units found, which prunes its remaining rows ----
-      const bool need_far = in_box && went_far;
-      if (listed && __any(need_far)) {  // wave-uniform
-        int li = sub;
-        bool more = need_far;
-        for (;;) {
-          if (lane == 0) S.q_tail = 0, S.q_head = 0;
-          wave_lds_sync();
-          if (more) {
-            const float lim = fminf(best, a.gate_sq_f);
-            for (; li < nlive; li += G) {
-              const int4 rec = S.live[li];
-              if (row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, cy, cz, qy, qz) > lim) continue;
-              const int slot = atomicAdd(&S.q_tail, 1);
-              if (slot >= kUnitCap) break;  // this row waits for the next round
-              S.unit_q[slot] = grp | (li << 5);
-              ++dbg_rows;
-            }
-            more = li < nlive;
-          }
-          wave_lds_sync();
-          {
-            const int tail = min(S.q_tail, kUnitCap);
-            const int ql = lane % kWalkLanes;
-            for (;;) {
-              int u = 0;
-              if (ql == 0) u = atomicAdd(&S.q_head, 1);
-              if constexpr (kWalkLanes > 1) u = quad_perm_i<0x00>(u);
-              if (u >= tail) break;
-              const int unit = S.unit_q[u], qs = unit & 31;
-              const int4 rec = S.live[unit >> 5];
-              const float4 q = S.qtab[qs];
-              int ux, uy, uz;
-              cell_coords(g, q.x, q.y, q.z, ux, uy, uz);
-              const float gyz = row_gap_sq(g, rec.x & 0xffff, rec.x >> 16, uy, uz, q.y, q.z);
-              const unsigned long long k0 = S.qkey[qs];
-              float ub = __uint_as_float((unsigned int)(k0 >> 32));
-              int up = (int)(unsigned int)k0;
-              if (gyz > fminf(ub, a.gate_sq_f)) continue;
-              // start where qx sits among the batch box's x-cells of the row (their bounds came with the listing: no round trip
-              // here; the walk is over the whole row either way, the start is only where it begins)
-              const int s0 = rec.z + (rec.w & 0xffff), e0 = rec.z + (int)((unsigned int)rec.w >> 16);
-              const float frac3 = fminf(fmaxf((q.x - (g.ox + (float)b0x * g.h)) / ((float)(b1x + 1 - b0x) * g.h), 0.f), 1.f);
-              const unsigned int c_before = ncand;
-              const unsigned int steps_before2 = dbg_g2;
-              if constexpr (kWalkLanes == 1) scan_global_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2);
-              else scan_quad_outward<kWin, kSideStep>(a.tgt3, rec.z, rec.z + rec.y, s0 + (int)(frac3 * (float)(e0 - s0)), q.x, q.y, q.z, gyz, a.gate_sq_f, ub, up, ncand, dbg_g2, ql);
-              if (ql == 0) {
-                if (a.dbg_qstats) atomicAdd(reinterpret_cast<int*>(a.dbg_qstats + a.n_src) + 64 + min((int)((dbg_g2 - steps_before2) & 0xffff), 63), 1);  // diagnostic: window steps per listed-row unit
-                atomicMin(&S.qkey[qs], pack_key(ub, up));
-                if (a.dbg_qstats) {
-                  atomicAdd(&S.qstat[qs][2], (int)(ncand - c_before));
-                  atomicAdd(&S.qstat[qs][1], 1 << 16);
-                }
-              }
-            }
-          }
-          wave_lds_sync();
-          if (in_box) {
-            const unsigned long long k1 = S.qkey[grp];
-            best = __uint_as_float((unsigned int)(k1 >> 32));
-            pos = (int)(unsigned int)k1;
-          }
-          if (!__any(more)) break;
-        }
-      }
-      NG_STAMP(5);
-      if (a.dbg_stamps && qok) {
-        unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
-        atomicMax(&d[14], ((unsigned long long)(dbg_g2 & 0xffff) << 48) | ((unsigned long long)(dbg_g2 >> 16) << 32) | ((unsigned long long)dbg_rows << 16) | (ncand - dbg_c1));
-        atomicMax(&d[15], ((unsigned long long)(dbg_g1 & 0xffff) << 48) | ((unsigned long long)(dbg_g1 >> 16) << 32) | dbg_c1);
-      }
-      // whatever lies beyond the listed rings: rare, per query
-      const unsigned int c_before_shells = ncand;
-      if (qok) nn_shells<G>(g, a.tgt3, a.tgt_cell_start, qx, qy, qz, cx, cy, cz, a.gate_sq_f, sub, need_far ? grow : 1, best, pos, ncand);
-      if (a.dbg_qstats) {  // wave-uniform
-        if (qok) atomicAdd(&S.qstat[grp][2], (int)(ncand - c_before_shells));
-        wave_lds_sync();
-        if (qok && sub == 0) a.dbg_qstats[qi] = make_int4(S.qstat[grp][0], S.qstat[grp][1], S.qstat[grp][2], (went_far ? 1 : 0) | (in_box ? 2 : 0) | (pos >= 0 ? 4 : 0));
-      }
-      {
-        const bool any_far = __any(went_far);
-        if (lane == 0) a.batch_far[batch] = any_far ? 1 : 0;
-      }
-      NG_STAMP(6);
-      // hand query g's result to lane g
-      const int src_lane = (lane % B) * G;
-      mybest = __shfl(best, src_lane);
-      mypos = __shfl(pos, src_lane);
-    }
-    double acc[kNumSums];
-#pragma unroll
-    for (int v = 0; v < kNumSums; ++v) acc[v] = 0.0;
-    if ((a.mode & 16) && mine) {  // DEBUG timing build: skip the FP64 tail
-      tpt_new[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(mypos));
-      acc[27] += (double)mybest;
-    } else if (mine) {
-      const double ax = (double)sp.x, ay = (double)sp.y, az = (double)sp.z;
-      // T * a in FP64 (impl/nano_gicp_impl.hpp:238,289)
-      const double tax = R[0] * ax + R[1] * ay + R[2] * az + t[0];
-      const double tay = R[3] * ax + R[4] * ay + R[5] * az + t[1];
-      const double taz = R[6] * ax + R[7] * ay + R[8] * az + t[2];
-
-      acc[28] += k4;  // K4, evaluated before the search
-      if (do_lin) {
-        const int pos = mypos;
-        const bool valid = (pos >= 0) && ((double)mybest < a.gate_sq);  // impl/nano_gicp_impl.hpp:195
-        if (!valid) tpt_new[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        if (valid) {
-          ++nvalid;
-          // Mahalanobis: (C_B + R C_A R^T)^-1  (impl/nano_gicp_impl.hpp:205-209)
-          const double* CB = a.cov_tgt + (size_t)pos * 6;
-          const double* CA = a.cov_src + (size_t)__float_as_int(sp.w) * 6;  // same round trip as the target's
-          const Xyz bp = a.tgt3[pos];
-          double ca[6];
-#pragma unroll
-          for (int e = 0; e < 6; ++e) ca[e] = CA[e];
-          tpt_new[i] = make_float4(bp.x, bp.y, bp.z, __int_as_float(pos));
-          double rcr[6], M[6];
-          rotate_sym(R, ca, rcr);
-#pragma unroll
-          for (int e = 0; e < 6; ++e) rcr[e] = CB[e] + rcr[e];
-          inv3_sym(rcr, M);
-          double* Mo = mahal_new + (size_t)i * 6;
-#pragma unroll
-          for (int e = 0; e < 6; ++e) Mo[e] = M[e];
-
-          // K3: residual, Jacobian, normal equations (impl/nano_gicp_impl.hpp:232-257)
-          const double ex = (double)bp.x - tax, ey = (double)bp.y - tay, ez = (double)bp.z - taz;
-          const double m00 = M[0], m01 = M[1], m02 = M[2], m11 = M[3], m12 = M[4], m22 = M[5];
-          const double mex = m00 * ex + m01 * ey + m02 * ez;
-          const double mey = m01 * ex + m11 * ey + m12 * ez;
-          const double mez = m02 * ex + m12 * ey + m22 * ez;
-          acc[27] += ex * mex + ey * mey + ez * mez;
-          // J = [S | -I], S = skew(Ta).   A = S*M  (column j of A = Ta x M[:,j]) = H_rot,trans block
-          const double A00 = tay * m02 - taz * m01, A10 = taz * m00 - tax * m02, A20 = tax * m01 - tay * m00;
-          const double A01 = tay * m12 - taz * m11, A11 = taz * m01 - tax * m12, A21 = tax * m11 - tay * m01;
-          const double A02 = tay * m22 - taz * m12, A12 = taz * m02 - tax * m22, A22 = tax * m12 - tay * m02;
-          // H_rr = S^T M S = -(A S);  S columns: (0,az,-ay) (-az,0,ax) (ay,-ax,0)
-          acc[0] += -(A01 * taz - A02 * tay);   // (0,0)
-          acc[1] += -(-A00 * taz + A02 * tax);  // (0,1)
-          acc[2] += -(A00 * tay - A01 * tax);   // (0,2)
-          acc[6] += -(-A10 * taz + A12 * tax);  // (1,1)
-          acc[7] += -(A10 * tay - A11 * tax);   // (1,2)
-          acc[11] += -(A20 * tay - A21 * tax);  // (2,2)
-          // H_rt = -S^T M = S M = A   rows 0..2, cols 3..5
-          acc[3] += A00; acc[4] += A01; acc[5] += A02;
-          acc[8] += A10; acc[9] += A11; acc[10] += A12;
-          acc[12] += A20; acc[13] += A21; acc[14] += A22;
-          // H_tt = M
-          acc[15] += m00; acc[16] += m01; acc[17] += m02;
-          acc[18] += m11; acc[19] += m12;
-          acc[20] += m22;
-          // b = J^T M e = [ S^T Me ; -Me ],  S^T v = v x Ta
-          acc[21] += mey * taz - mez * tay;
-          acc[22] += mez * tax - mex * taz;
-          acc[23] += mex * tay - mey * tax;
-          acc[24] += -mex;
-          acc[25] += -mey;
-          acc[26] += -mez;
-        }
-      }
-    }
-    // ---- R0: per-batch reduction through LDS (the row tables are idle now): lanes 0..31 hold the tail's sums; sixteen of
-    //      them at a time write a row of a [16][30] tile, lane v then adds column v in fixed order (queries 0, 1, ... 31:
-    //      deterministic).  A butterfly of 64-bit shuffles here costs ~350 dependent LDS-crossbar round trips; a [32][30] tile
-    //      costs the LDS that a fourth block per CU needs.
-    {
-      double* red = S.red;  // [16][30] doubles
-      double out = 0.0;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        wave_lds_sync();
-        if ((lane >> 4) == half) {
-#pragma unroll
-          for (int v = 0; v < kNumSums; ++v) red[(lane & 15) * 30 + v] = acc[v];
-        }
-        wave_lds_sync();
-        if (lane < kNumSums)
-          for (int l = 0; l < 16; ++l) out += red[l * 30 + lane];
-      }
-      if (lane < kNumSums) wave_total += out;
-    }
-  }
-
-  NG_STAMP(7);
-  {
-    // counters: [3][64] through LDS, lanes 29..31 add their column
-    wave_lds_sync();
-    unsigned int* cnt = reinterpret_cast<unsigned int*>(S.red);
-    cnt[lane] = ncand;
-    cnt[64 + lane] = nvalid;
-    cnt[128 + lane] = nstaged;
-    wave_lds_sync();
-    if (lane >= kNumSums && lane < kNumSlots) {
-      unsigned int sum = 0;
-      for (int l = 0; l < 64; ++l) sum += cnt[(lane - kNumSums) * 64 + l];
-      wave_total = (double)sum;
-    }
-    if (lane < kNumSlots) lds[wave][lane] = wave_total;
-  }
-  NG_STAMP(8);
-  __syncthreads();
-  NG_STAMP(9);
-  if (threadIdx.x < kNumSlots) {
-    const int v = threadIdx.x;
-    const double val = ((lds[0][v] + lds[1][v]) + lds[2][v]) + lds[3][v];
-    // fused: write-through (agent-scope store: nothing stays dirty in this XCD's L2, no release fence and no L2 write-back needed)
-    if (FUSED) __hip_atomic_store(a.partials + (size_t)group * kNumSlots + v, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else a.partials[(size_t)group * kNumSlots + v] = val;
-  }
-  if (a.dbg_span && threadIdx.x == 0) {
-    unsigned long long* d = a.dbg_span + (size_t)blockIdx.x * 4;
-    d[1] = __builtin_amdgcn_s_memrealtime();
-    d[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID, XCC_ID
-    d[3] = (unsigned long long)(unsigned int)group;
-  }
-  if (a.grp_cost && threadIdx.x == 0) {
-    const int cost = (int)min((__builtin_amdgcn_s_memtime() - t_start) >> 4, 0x7fffffffull);
-    if (FUSED) __hip_atomic_store(a.grp_cost + group, cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else a.grp_cost[group] = cost;
-  }
+#define NG_HAVE_LIN st->hot.have_lin
+#include "ngicp_pass_group.inc"
+#undef NG_HAVE_LIN
   if constexpr (FUSED) {
   // ---- the solver in the tail of the launch (R0's final sum, impl/nano_gicp_impl.hpp:260-267, and LsqRegistration's step,
   //      impl/lsq_registration_impl.hpp:161-208).  Every store of this block that another block will read was made by wave 0 as a
@@ -1497,6 +1073,162 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   }
   __syncthreads();
   lm_solve_body<256, true>(a.sa, shm.sv);
+  }
+}
+
+// One group of one pass for the PERSISTENT kernel, which calls it once per group and pass (a function of its own: inlined into that
+// kernel's loops, everything the loops keep alive pushed the search's registers into scratch memory - 2.5x the time per pass).  The
+// arguments are read where the hardware put them, through the constant address space (a.field is then a scalar load the compiler may
+// repeat instead of keeping the value, exactly as in a kernel of its own); the trial pose comes from entry pass_no of the ring of views.
+template <int G, int WPS, class A>
+__device__ __forceinline__ void persist_group_body(A& a, const int group, const int pass_no, WaveStage* stage_all, double (*lds)[kNumSlots]) {
+  constexpr bool FUSED = true;  // (the block's row and cost are stored write-through)
+  constexpr int B = 64 / G;
+  constexpr int kWin = WPS >= 4 ? 12 : 16, kSideStep = WPS >= 4 ? 8 : 16;  // (see k_gicp_pass)
+  static_assert(kWin <= kSortedPad && B == kBatchQueries, "see k_gicp_pass");
+  const bool do_lin = (a.mode & 2);
+  Grid g;  // (field by field: a reference to a generic Grid cannot bind to the constant address space)
+  g.ox = a.grid.ox; g.oy = a.grid.oy; g.oz = a.grid.oz;
+  g.h = a.grid.h; g.inv_h = a.grid.inv_h;
+  g.nx = a.grid.nx; g.ny = a.grid.ny; g.nz = a.grid.nz;
+  g.ncells = a.grid.ncells;
+  g.slack = a.grid.slack;
+  // the pass's view of the state: entry pass_no of the ring (see LmState::view) - it does not change while the pass runs
+  typedef const int __attribute__((address_space(4))) * ViewPtr;
+  typedef const double __attribute__((address_space(4))) * ViewPtrD;
+  typedef const float __attribute__((address_space(4))) * ViewPtrF;
+  ViewPtr vw = (ViewPtr)(unsigned long long)(a.st->view + (size_t)(a.first_pass + pass_no) * kViewWords);
+  const int have_lin = vw[kViewHaveLin];
+  const int cur = vw[kViewCur] & 1, nxt = cur ^ 1;  // (indices into two-element arrays of pointers, whatever the memory holds)
+  ViewPtrD vx = (ViewPtrD)(vw + kViewXi);
+  ViewPtrF vf = (ViewPtrF)(vw + kViewXiF);
+  double R[9], t[3];
+  float Tf[12];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = vx[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = vx[9 + i];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Tf[i] = vf[i];
+  const bool do_err = (a.mode & 1) && have_lin;
+  const float4* __restrict__ tpt_old = a.tpt[cur];
+  const double* __restrict__ mahal_old = a.mahal[cur];
+  float4* __restrict__ tpt_new = a.tpt[nxt];
+  double* __restrict__ mahal_new = a.mahal[nxt];
+  double wave_total = 0.0;
+  unsigned int ncand = 0, nvalid = 0, nstaged = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % G, grp = lane / G;
+  WaveStage& S = stage_all[wave];
+  NG_STAMP(0);
+  const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
+#define NG_HAVE_LIN have_lin
+#include "ngicp_pass_group.inc"
+#undef NG_HAVE_LIN
+}
+
+// ---- the persistent kernel: ONE launch per alignment.  A thin loop over passes and over the block's groups around two CALLED functions
+//      (the group body above, the solver): what the loop keeps alive does not compete with the search for registers.  The functions
+//      find the kernel's arguments where the hardware put them (the kernel-argument segment), and share the block's LDS as
+//      namespace-scope variables (allocated to this kernel only). ----
+union PersistShared {
+  WaveStage stage[4];
+  SolveShared<256> sv;  // the solver (the last block to arrive) works where the search tables were
+};
+__shared__ PersistShared g_persist_shm;
+__shared__ double g_persist_lds[4][kNumSlots];
+__shared__ int g_persist_last;
+typedef const PassArgs __attribute__((address_space(4))) KernelPassArgs;
+
+// (ka: the kernel's argument segment, handed down by the kernel itself - inside a called function __builtin_amdgcn_kernarg_segment_ptr()
+// is the pointer to the kernel's IMPLICIT arguments, behind the explicit ones)
+// (Arguments of a called function arrive in vector registers: made wave-uniform again with v_readfirstlane, so that a.field is a
+// scalar load and group / pass_no live in scalar registers.)
+__device__ __forceinline__ KernelPassArgs* uniform_args(KernelPassArgs* ka) {
+  const unsigned long long v = (unsigned long long)ka;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return (KernelPassArgs*)(((unsigned long long)hi << 32) | lo);
+}
+template <int G, int WPS>
+__device__ __attribute__((noinline)) void persist_group_call(KernelPassArgs* ka, int group, int pass_no) {
+  persist_group_body<G, WPS>(*uniform_args(ka), __builtin_amdgcn_readfirstlane(group), __builtin_amdgcn_readfirstlane(pass_no), g_persist_shm.stage, g_persist_lds);
+}
+
+__device__ __attribute__((noinline)) void persist_solve_call(KernelPassArgs* ka) {
+  const char* kargs = (const char*)uniform_args(ka);
+  lm_solve_body<256, true, true>(*reinterpret_cast<const SolveArgs*>(kargs + offsetof(PassArgs, sa)), g_persist_shm.sv);
+}
+
+template <int G, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_gicp_persist(PassArgs a) {
+  KernelPassArgs* ka = (KernelPassArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // == &a: where the hardware put the arguments
+  const bool ordered = a.grp_order && a.order_valid && *a.order_valid;  // (fixed for the whole alignment: the solver builds the NEXT alignment's order)
+  const int n_groups = (a.n_batches + 3) / 4;
+  for (int pass_no = 0; pass_no < a.max_passes; ++pass_no) {
+    {
+      // (the address is made opaque HERE, behind the wait that released the pass: no load of the entry can be placed earlier)
+      const int* vw_g = a.st->view + (size_t)(a.first_pass + pass_no) * kViewWords;
+      asm volatile("" : "+s"(vw_g));
+      typedef const int __attribute__((address_space(4))) * ViewPtr;
+      ViewPtr vw = (ViewPtr)(unsigned long long)vw_g;
+      if (vw[kViewDone]) break;
+      if (a.t_first && blockIdx.x == 0 && threadIdx.x == 0 && !vw[kViewHaveLin])
+        __hip_atomic_store(a.t_first, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // The grid is as many blocks as are resident together; block b takes the positions b, 2P - 1 - b, 2P + b, ... of the launch order
+    // (heaviest first, then back and forth), the same ones in every pass: a group's correspondences and Mahalanobis matrices stay
+    // in its block's CU / XCD from pass to pass.
+    for (int turn = 0;; ++turn) {
+      const int slot = turn * (int)gridDim.x + ((turn & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+      if (slot >= n_groups) break;
+      __syncthreads();  // (the block's row of sums in LDS has been read)
+      persist_group_call<G, WPS>(ka, ordered ? a.grp_order[slot] : slot, pass_no);
+    }
+    // ---- the blocks meet here after every pass.  Every store of this block that another block will read was made by wave 0 as a
+    //      write-through store; wave 0 drains them, then one lane takes a ticket (relaxed, agent scope; the ticket counts on, pass after
+    //      pass).  The last block to arrive steps the optimiser (no fence: lm_solve_body<.., PERSIST> reads what other blocks wrote with
+    //      agent-scope loads and stores the state write-through), then releases the next pass; the others wait for that with one
+    //      polling lane each.  Every block of the grid is resident (the host sizes the grid by the occupancy of this very kernel and
+    //      launches it cooperatively), the wait is bounded all the same: a block that gives up raises `gen` to a value no pass reaches,
+    //      so that every other block leaves too and the grid drains. ----
+    constexpr int kGenFailed = 1 << 30;
+    if (threadIdx.x < 64) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g_persist_last = (tk == (pass_no + 1) * (int)gridDim.x - 1) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    static_assert(kGenLines == 256, "one thread of the releasing block per copy of the release word");
+    if (g_persist_last) {  // (block-uniform)
+      if (a.sa.pass_ticks && threadIdx.x == 0) a.sa.pass_ticks[2 * pass_no] = __builtin_amdgcn_s_memrealtime();
+      persist_solve_call(ka);
+      if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the state image and the next view were stored by wave 0: its own counter covers them)
+      __syncthreads();
+      if (a.sa.pass_ticks && threadIdx.x == 0) a.sa.pass_ticks[2 * pass_no + 1] = __builtin_amdgcn_s_memrealtime();
+      __hip_atomic_fetch_max(a.gen + threadIdx.x * kGenStride, pass_no + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) g_persist_last = 0;
+    } else if (a.persist == 2) {
+      return;  // (A/B measurement only, one pass per launch: nobody waits)
+    } else if (threadIdx.x == 0) {
+      // (every poll goes out to memory, and the blocks still working feel ~770 pollers: c3 41 us per pass at one poll per microsecond
+      // and block, 36-37 at one per 3.4 us - s_sleep's maximum; sleeping without polls for 3/4 of the previous period first: no better)
+      const int* my_gen = a.gen + ((int)blockIdx.x % kGenLines) * kGenStride;
+      int seen = 0;
+      for (int spin = 0; spin < (1 << 20); ++spin) {  // (~5 s)
+        seen = __hip_atomic_load(my_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen > pass_no) break;
+        __builtin_amdgcn_s_sleep(127);
+      }
+      g_persist_last = (seen <= pass_no || seen >= kGenFailed) ? 2 : 0;
+    }
+    __syncthreads();
+    if (g_persist_last == 2) {  // (block-uniform; the host sees no done flag and falls back to one launch per pass)
+      __hip_atomic_fetch_max(a.gen + threadIdx.x * kGenStride, kGenFailed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __syncthreads();  // (g_persist_last is written again in the next pass)
   }
 }
 #undef NG_STAMP

@@ -17,6 +17,10 @@ g.setMaxCorrespondenceDistance(float(os.environ.get("NGICP_GATE", w.max_corr_dis
 g.setMaximumIterations(20); g.setTransformationEpsilon(1e-12); g.setRotationEpsilon(1e-12)
 g.setInputTarget(w.target); g.setInputSource(w.source)
 g.calculateTargetCovariances(); g.calculateSourceCovariances()
+if os.environ.get("PROF"):
+    g.setProfiling(int(os.environ["PROF"]))  # every PROF-th pass timed (events, or the persistent kernel's own stamps)
 for r in range(reps):
     g.align(w.guess); s = g.stats()
+    if os.environ.get("PROF") and s["passes_timed"]:
+        print(f"   passes timed {s['passes_timed']}: mean {1e3 * s['pass_ms_total'] / s['passes_timed']:.2f} us; loop - passes = {1e3 * (s['loop_ms'] - s['pass_ms_total'] * s['passes'] / s['passes_timed']) / s['passes']:.2f} us per pass")
     print(f"align {s['align_ms']:.3f} ms loop {s['loop_ms']:.3f} passes {s['passes']} iters {s['outer_iterations']} Cbar {s['mean_candidates']:.1f} h {s['voxel_size']:.3f} lanes {s['lanes_per_query']} staged {s['staged_fraction']:.3f}", flush=True)

@@ -467,6 +467,35 @@ def test_full_size_properties(ng):
         assert np.allclose(tr[:, 4], runs[0][1][:, 4], atol=1e-2)
 
 
+@pytest.mark.parametrize("case", ["dlo_s2s", "fixed20", "gauss_newton", "one_iteration"])
+def test_persistent_kernel_equals_one_launch_per_pass(ng, monkeypatch, case):
+    """NGICP_PERSIST=1 (ONE launch per alignment: the blocks keep their groups, meet after every pass, the last one steps the optimiser)
+    against the default (one pass launch + one solver launch per iteration): the same sums in the same order, so everything is
+    bit-identical - pose, Hessian, trace, correspondences.  A 100k-point source has more groups (866) than the persistent grid has
+    blocks (768): some blocks take two groups per pass; 10k points leave most of the grid's blocks without a group of their own."""
+    for w in (clouds.scan_to_scan(10_000), clouds.scan_to_submap(100_000, 5)):
+        if len(w.source) > 50_000 and case not in ("fixed20", "one_iteration"):
+            continue
+        out = []
+        for persist in ("0", "1"):
+            monkeypatch.setenv("NGICP_PERSIST", persist)  # (read when the handle is created)
+            g = ng.NanoGICP(); g.setMaxCorrespondenceDistance(w.max_corr_dist)
+            for k, v in CASES[case].items():
+                getattr(g, k)(v)
+            g.setInputTarget(w.target); g.setInputSource(w.source)
+            runs = []
+            for _ in range(3):  # (the second and third alignment launch in the order the one before left behind)
+                g.align(w.guess)
+                runs.append((g.getFinalTransformation().copy(), g.getFinalHessian().copy(), g.lm_trace().copy(), g.nr_iterations_, g.converged_, g.stats()["passes"]))
+            corr = g.correspondences()
+            out.append((runs, corr))
+        monkeypatch.delenv("NGICP_PERSIST")
+        for (a, b) in zip(out[0][0], out[1][0]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:]
+        assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+        assert out[0][0][0][5] >= 1
+
+
 # ------------------------------------------------------------------ the small FP64 routines, directly on the device (SURVEY §8 a12)
 def test_device_math_matches_oracle(ng, oracle_mod):
     """so3_exp (both branches: the Taylor series for theta^2 < 1e-10 and the sin / cos form, gicp/so3.hpp:99-118), the 6x6 LDLT
