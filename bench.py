@@ -173,10 +173,11 @@ def submap_routes_ms(ng, w, device, reps=3):
         kfe.setInputSource(np.ascontiguousarray(filt[:, :3])); kfe.calculateSourceCovariances(); normals_kf = kfe.getSourceCovariances()  # odom.cc:1172-1174
         t1 = time.perf_counter()
         kfe.close()
+        t1b = time.perf_counter()  # (closing the host route's scratch handle belongs to neither route)
         kid = s2m.addKeyframeTransformedFiltered(s2s, T, 0.5); s2m.stats()
         t2 = time.perf_counter()
         if r:
-            t_kf_host.append((t1 - t0) * 1e3); t_kf_dev.append((t2 - t1) * 1e3)
+            t_kf_host.append((t1 - t0) * 1e3); t_kf_dev.append((t2 - t1b) * 1e3)
     kf_points = s2m.keyframeSize(kid)
     s2s.close(); s2m.close()
     return {"host_route_ms": statistics.median(t_host), "device_route_ms": statistics.median(t_dev), "keyframes": len(kfs), "points": int(len(w.target)),

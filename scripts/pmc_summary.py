@@ -10,8 +10,8 @@ os.makedirs(DST, exist_ok=True)
 
 
 def one(pattern):
-    fs = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return fs[0] if fs else None
+    fs = glob.glob(os.path.join(SRC, pattern), recursive=True)  # (gpurun merges into what is already there: earlier runs' files stay)
+    return max(fs, key=os.path.getmtime) if fs else None
 
 
 stats = one("trace/**/*kernel_stats.csv")

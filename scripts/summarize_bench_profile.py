@@ -2,17 +2,17 @@
 averages of the two hot kernels, which the bench line's HIP-event figure must agree with)."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", "prof_bench")
 DST = os.path.join(ROOT, "profiles")
-stats = glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+stats = max(glob.glob(os.path.join(SRC, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # (the newest: gpurun merges into what is there)
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(DST, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in rows:
         w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-trace = glob.glob(os.path.join(SRC, "trace", "**", "*kernel_trace.csv"), recursive=True)[0]
+trace = max(glob.glob(os.path.join(SRC, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 durs = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     durs[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

@@ -41,11 +41,17 @@ def _frames(ng, w, scans):
     return out, covs
 
 
-def test_handles_on_concurrent_threads_give_the_serial_results(ng):
+@pytest.mark.parametrize("persist", ["0", "1"])
+def test_handles_on_concurrent_threads_give_the_serial_results(ng, monkeypatch, persist):
+    """persist = 1: the handles ask for the persistent registration kernel (NGICP_PERSIST, read at ngicp_create).  One alignment per
+    device at a time takes that route (its grid fills the device and its blocks wait for each other); a handle that finds it taken runs
+    one launch per pass beside it.  Either route gives the same bits."""
     w = clouds.scan_to_submap(20_000, 3)
     n_threads, n_frames = 4, 5
     scans = [[np.ascontiguousarray(w.source + np.float32(1e-3 * (5 * t + i))) for i in range(n_frames)] for t in range(n_threads)]
+    monkeypatch.setenv("NGICP_PERSIST", "0")
     serial = [_frames(ng, w, scans[t]) for t in range(n_threads)]
+    monkeypatch.setenv("NGICP_PERSIST", persist)
     results, errors = [None] * n_threads, []
 
     def work(t):
