@@ -289,6 +289,9 @@ struct ngicp {
   int order_sel = 0;     // which of the two launch-order buffers (and flag words) the next alignment reads
   DevBuf grp_order_alt;  // the second order buffer: the persistent kernel's solver builds the NEXT alignment's order there
   DevBuf gen_lines;      // the persistent kernel's release word, kGenLines copies (PassArgs::gen)
+  int head = 0;          // env NGICP_HEAD=1: k_gicp_head - no solver launch, every block steps the optimiser at its head
+  DevBuf state_alt;      // k_gicp_head: the second state buffer (a launch's solver block writes the one its blocks are not reading)
+  DevBuf head_ws;        // k_gicp_head: {done flag (64 B), subset tickets (128 B), subset rows of even / odd launches (2 x 8 KB)}
   unsigned long long* pin_ticks = nullptr;  // pinned [2 * kMaxTickPasses]: per pass {last block arrived, next pass released} (profiling)
   double prev_staged_fraction = -1.0;  // share of the queries the previous alignment served through row lists (-1: none yet)
   DevBuf dbg, dbg_q, dbg_s, dbg_span, grp_order, grp_cost, batch_far;
@@ -834,6 +837,12 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   s.t_first = nullptr;
   s.persist = 0;
   s.pass_ticks = nullptr;
+  s.st_out = nullptr;
+  s.nrows = 0;
+  a.crow_in = nullptr;
+  a.crow_out = nullptr;
+  a.cluster_ticket = nullptr;
+  a.done_flag = nullptr;
   c.nblocks = nblocks;
   h->stats.lanes_per_query = 2;
   h->stats.voxel_size = T.grid.h;
@@ -967,8 +976,8 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
 
   const char* stamp_path = std::getenv("NGICP_DEBUG_STAMPS");  // diagnostic only
   if (stamp_path) {
-    h->dbg.ensure((size_t)c.nblocks * 4 * kStampStride * sizeof(unsigned long long));
-    HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)c.nblocks * 4 * kStampStride * sizeof(unsigned long long), h->stream));
+    h->dbg.ensure((size_t)(c.nblocks + 1) * 4 * kStampStride * sizeof(unsigned long long));  // (k_gicp_head has one block more)
+    HIP_TRY(hipMemsetAsync(h->dbg.p, 0, (size_t)(c.nblocks + 1) * 4 * kStampStride * sizeof(unsigned long long), h->stream));
     c.pa.dbg_stamps = h->dbg.as<unsigned long long>();
   }
   if (std::getenv("NGICP_DEBUG_SOLVE")) {  // diagnostic only: s_memtime stamps of the last solver launch, printed after the align
@@ -1092,7 +1101,32 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       *h->h_progress = 0;
     }
   }
-  while (!finished && launched < max_passes) {
+  // ---- NGICP_HEAD=1: no solver launch at all (k_gicp_head): one launch per iteration, and one more whose head consumes the last pass ----
+  const bool head_mode = h->head && !finished && pass_impl() == 0 && !c.pa.fused && !xcd_order && !span_path && !qstat_path && !c.sa.dbg_stamps &&
+                         c.nblocks <= 2 * h->pass_slots;  // (grids of more rounds: the head's few microseconds are paid once per round)
+  LmState* head_state[2] = {nullptr, nullptr};
+  double* head_crow[2] = {nullptr, nullptr};
+  int *head_tickets = nullptr, *head_done = nullptr, *head_order[2] = {nullptr, nullptr}, *head_flag[2] = {nullptr, nullptr};
+  if (head_mode) {
+    h->state_alt.ensure(sizeof(LmState));
+    const size_t crow_bytes = (size_t)kSolveRowSubsets * kNumSlots * sizeof(double);
+    h->head_ws.ensure(64 + 128 + 2 * crow_bytes);
+    HIP_TRY(hipMemsetAsync(h->head_ws.p, 0, 64 + 128 + 2 * crow_bytes, h->stream));
+    unsigned char* ws = h->head_ws.as<unsigned char>();
+    head_done = reinterpret_cast<int*>(ws);
+    head_tickets = reinterpret_cast<int*>(ws + 64);
+    head_crow[0] = reinterpret_cast<double*>(ws + 192);
+    head_crow[1] = reinterpret_cast<double*>(ws + 192 + crow_bytes);
+    head_state[0] = h->state.as<LmState>();
+    head_state[1] = h->state_alt.as<LmState>();
+    int* const ctl = h->order_flag.as<int>();
+    head_order[0] = h->grp_order.as<int>();
+    head_order[1] = h->grp_order_alt.as<int>();
+    head_flag[0] = ctl;
+    head_flag[1] = ctl + 3;
+  }
+  const long max_launches = head_mode ? max_passes + 1 : max_passes;
+  while (!finished && launched < max_launches) {
     const int prog = *reinterpret_cast<volatile int*>(h->h_progress);
     if (prog & kProgressDone) break;
     if (launched - (long)(prog & kProgressMask) >= depth) {  // enough in flight: wait for the device to catch up
@@ -1101,6 +1135,29 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
       continue;
     }
     const bool timed = h->profiling && launched % h->prof_stride == h->prof_stride / 2 && (size_t)(2 * launched + 1) < h->prof_events.size();
+    if (head_mode) {
+      // k_gicp_head: launch i reads state / subset rows / launch order [i & 1] and leaves the next ones in [(i + 1) & 1]
+      const int par = (int)(launched & 1);
+      PassArgs pa = c.pa;
+      pa.st = head_state[par];
+      pa.crow_in = head_crow[par];
+      pa.crow_out = head_crow[par ^ 1];
+      pa.cluster_ticket = head_tickets;
+      pa.done_flag = head_done;
+      pa.grp_order = head_order[par];
+      pa.order_valid = head_flag[par];
+      pa.sa = c.sa;
+      pa.sa.st = head_state[par];
+      pa.sa.st_out = head_state[par ^ 1];
+      pa.sa.partials = head_crow[par];
+      pa.sa.nrows = kSolveRowSubsets;
+      pa.sa.grp_order = head_order[par ^ 1];
+      pa.sa.order_valid = head_flag[par ^ 1];
+      hipExtLaunchKernelGGL((k_gicp_head<2, 3>), dim3((unsigned)c.nblocks + 1), dim3(256), 0, h->stream, timed ? h->prof_events[2 * launched] : nullptr,
+                            timed ? h->prof_events[2 * launched + 1] : nullptr, 0, pa);
+      ++launched;
+      continue;
+    }
     static const bool persist_one = std::getenv("NGICP_PERSIST_ONE") != nullptr;  // A/B only: the persistent kernel's code, one launch per pass
     if (persist_one && h->persist_slots > 0 && max_passes + 1 <= kMaxPersistPasses) {
       PassArgs pa = c.pa;
@@ -1133,17 +1190,20 @@ void do_align(ngicp* h, const float guess[16], float* aligned, size_t out_stride
     for (;;) {
       const int prog = __atomic_load_n(h->h_progress, __ATOMIC_ACQUIRE);
       if (prog & kProgressDone) break;
-      if (launched >= max_passes && launched - (long)(prog & kProgressMask) <= 0) break;  // (cannot happen: the last possible pass sets done)
+      if (launched >= max_launches && launched - (long)(prog & kProgressMask) <= 0) break;  // (cannot happen: the last possible pass sets done)
       if ((++spins & (h->host_wait ? 0xfff : 0xfffff)) == 0 && now_ms() - t_loop > 30000.0) throw ArgError{NGICP_ERR_HIP, "the registration loop did not finish within 30 s"};
       if (h->host_wait) sched_yield(); else __builtin_ia32_pause();
     }
     st.hot = *h->pin_final;
     loop_ms = (float)((double)(st.hot.t_done - st.hot.t_first) * 1e-5);  // 100 MHz ticks -> ms
+    // (k_gicp_head: the head of launch `passes` ended the alignment and left the final state in the buffer it does not read; the handle's
+    // other entry points look for it in h->state)
+    if (head_mode && ((st.hot.passes + 1) & 1)) HIP_TRY(hipMemcpyAsync(h->state.p, h->state_alt.p, sizeof(LmState), hipMemcpyDeviceToDevice, h->stream));
   }
   HIP_TRY(hipGetLastError());
 
   if (stamp_path) {
-    std::vector<unsigned long long> hs((size_t)c.nblocks * 4 * kStampStride);
+    std::vector<unsigned long long> hs((size_t)(c.nblocks + 1) * 4 * kStampStride);
     HIP_TRY(hipMemcpy(hs.data(), h->dbg.p, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(stamp_path, "wb")) {
       std::fwrite(hs.data(), sizeof(unsigned long long), hs.size(), f);
@@ -1358,6 +1418,7 @@ int ngicp_create(int device, ngicp_t** out) {
     }
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_ticks), 2 * kMaxTickPasses * sizeof(unsigned long long), hipHostMallocDefault));
     if (const char* s = std::getenv("NGICP_PERSIST")) h->persist = std::atoi(s);
+    if (const char* s = std::getenv("NGICP_HEAD")) h->head = std::atoi(s);
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_CHUNK")) h->chunk_pairs = std::max(1, std::min(64, std::atoi(s)));

@@ -65,7 +65,7 @@ struct LmHot {
   int lm_failed;
   int n_trace;
   int passes;     // passes that did work
-  int pad_;
+  int pending;    // k_gicp_head only: the rows of a finished pass wait for the next launch's head to step the optimiser with them
   double final_H[36];  // H of the last accepted step, row-major (final_hessian_, impl/lsq_registration_impl.hpp:155,203); identity until then
   unsigned long long t_first, t_done;  // 100 MHz counter at the start of the alignment's first pass / when the solver set `done`
 };
@@ -134,6 +134,8 @@ struct SolveArgs {
   LmHot* final_host;       // pinned host memory, or null: the state image, written when the alignment is done, BEFORE the done flag goes out
   int* order_valid;        // device word: the solver has published a group order (heaviest first) for the next pass
   const unsigned long long* t_first;  // device word the first pass of an alignment stamps (100 MHz counter)
+  LmState* st_out;         // where the advanced state goes (null: back to st).  k_gicp_head: the blocks of the launch read st while its solver block writes
+  int nrows;               // rows of `partials` (0: nblocks, one per group).  k_gicp_head: 32 rows, already added up per subset by the pass's blocks
   int persist;             // the solver runs between two passes of ONE launch: every word other blocks (on other XCDs) wrote or will read
                            // goes through agent-scope loads / write-through stores, and the launch order it builds is for the NEXT alignment
   unsigned long long* pass_ticks;  // persist: [2 * max passes] 100 MHz ticks {last block arrived, next pass released} per pass, or null
@@ -178,6 +180,12 @@ struct PassArgs {
   // persistent: ONE launch per alignment.  A block keeps its groups for the whole alignment (their correspondences and Mahalanobis
   // matrices never leave its CU's L1 / its XCD's L2: no kernel boundary drops them), the blocks meet at the ticket after every pass,
   // the last one to arrive steps the optimiser and releases the next pass through `gen`.
+  // k_gicp_head: no solver launch.  Every block of launch i steps the optimiser itself, at its head, with the sums of pass i - 1 (32 rows,
+  // added up per subset of groups by the blocks that finished their subset last), then searches at the pose it has just computed.
+  const double* crow_in;   // [32][kNumSlots] the subset rows of the previous pass (zero rows for subsets without groups)
+  double* crow_out;        // [32][kNumSlots] this pass's
+  int* cluster_ticket;     // [32] zero before the launch; the last block of a subset puts its word back
+  int* done_flag;          // device word, zero at the start of an alignment: a launch's solver block sets it when the alignment is over
   int persist;
   int first_pass;  // (0 unless the kernel is launched once per pass for an A/B measurement: the ring entry the launch begins with)
   int max_passes;
@@ -507,6 +515,7 @@ constexpr int kSolveSubs = kSolveThreads / 16;  // sub-sums per slot pair (threa
 #endif
 constexpr int kSolveChunk = NGICP_SOLVE_CHUNK;                  // 16-byte loads a thread keeps in flight per step: one step covers 32 x 40 = 1280 groups
 
+constexpr int kSolveRowSubsets = 32;  // the solver adds the group rows in 32 subsets (row g belongs to subset g mod 32), then the subsets in order
 constexpr int kProgressDone = 1 << 30, kProgressMask = kProgressDone - 1;
 
 __device__ __forceinline__ bool is_converged_dev(const Pose& d, double rot_eps, double trans_eps) {  // impl/lsq_registration_impl.hpp:118-127
@@ -631,6 +640,40 @@ __device__ __forceinline__ bool lm_advance(LmHot& L, const LmConfig& cfg, const 
   return true;
 }
 
+// One step of the optimiser's state machine with the sums of a finished pass (the serial lane of the solver; k_gicp_head's blocks run it
+// redundantly, each for itself): lm_advance, and on an accepted trial the bookkeeping of LsqRegistration::align's outer loop.
+__device__ __forceinline__ void lm_step(LmHot& L, const LmConfig& cfg, const double* sums, double* trace, int max_trace_rows) {
+  const bool gn = cfg.optimizer == 0;
+  const bool accepted = lm_advance(L, cfg, sums, trace, max_trace_rows);
+  if (accepted) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) L.final_H[i] = L.H[i];
+    if (!gn) {
+      // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
+      double den = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
+      const double rho = (L.y0 - sums[28]) / den;
+      L.x0 = L.xi;
+      const double q = 2 * rho - 1;
+      L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - q * q * q);
+      L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
+      L.iter += 1;
+      if (L.converged || L.iter >= cfg.max_iterations) {
+        L.done = 1;
+      } else {
+        // the speculative linearisation at xi (== new x0) becomes current
+        adopt_new(L, sums);
+        L.nr_iterations = L.iter;
+        L.nu = 2.0;
+        L.trial = 0;
+        make_trial(L, L.lambda);
+      }
+    }
+  }
+  if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
+}
+
 // The solver's block-shared scratch.  k_lm_solve owns one; the fused tail of k_gicp_pass lays it over the (then idle) search tables.
 template <int THREADS>
 struct SolveShared {
@@ -668,6 +711,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   LmHot& L = sh.L;
   if (threadIdx.x == 0) ord_arrived = 0;  // (visible to every wave after the barriers below)
   LmState* st = a.st;
+  LmState* sto = a.st_out ? a.st_out : a.st;
 #define NG_SSTAMP(k)                                                                 \
   do {                                                                               \
     if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
@@ -702,7 +746,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   }
   // (One CU moves 64 B per clock: the 222 KB of 866 rows are ~3.5k cycles on top of the latency.  Rows beyond the grid are skipped by
   // a branch each: fetching a stand-in row instead - branch-free issue - measured slower, the stand-ins pile up on one channel.)
-  const int last_row = a.nblocks - 1;
+  const int last_row = (a.nrows ? a.nrows : a.nblocks) - 1, last_grp = a.nblocks - 1;
   // (AGENT: the caller's agent-scope acquire has dropped this CU's L1, the producers stored write-through and no line of these rows
   // can be in this XCD's L2 from before - nobody read them earlier in this launch: plain 16-byte loads, as MI355X_MICROARCH.md's
   // "valid forms" prescribe for the consumer side)
@@ -728,8 +772,8 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
 #pragma unroll
   for (int k = 0; k < kCostPerThread; ++k) {
     const int gi = threadIdx.x + k * kSolveThreads;
-    if constexpr (PERSIST) oc[k] = (order_it && gi <= last_row) ? __hip_atomic_load(a.grp_cost + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    else oc[k] = (order_it && gi <= last_row) ? a.grp_cost[gi] : 0;
+    if constexpr (PERSIST) oc[k] = (order_it && gi <= last_grp) ? __hip_atomic_load(a.grp_cost + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    else oc[k] = (order_it && gi <= last_grp) ? a.grp_cost[gi] : 0;
   }
   if (a.mode == 0 && done_at_entry) return;  // (a scalar load issued at the top: it does not wait for the vector loads above)
   // The serial lane works on the LDS image of the state in place (a register-resident copy needs ~260 VGPRs: it spills at two
@@ -886,38 +930,10 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
       adopt_new(L, sums);
     } else {
       const LmConfig& cfg = a.cfg;
-      const bool gn = cfg.optimizer == 0;
       NG_SSTAMP(3);
-      const bool accepted = lm_advance(L, cfg, sums, a.trace, a.max_trace_rows);
+      lm_step(L, cfg, sums, a.trace, a.max_trace_rows);
       NG_SSTAMP(4);
-      if (accepted) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) L.final_H[i] = L.H[i];
-        if (!gn) {
-          // LM accept: x0 = xi, lambda update, convergence, next outer iteration (impl/lsq_registration_impl.hpp:201-204,110)
-          double den = 0.0;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) den += L.d[i] * (L.lambda * L.d[i] - L.b[i]);
-          const double rho = (L.y0 - sums[28]) / den;
-          L.x0 = L.xi;
-          const double q = 2 * rho - 1;
-          L.lambda = L.lambda * fmax(1.0 / 3.0, 1 - q * q * q);
-          L.converged = is_converged_dev(L.delta, cfg.rot_eps, cfg.trans_eps) ? 1 : 0;
-          L.iter += 1;
-          if (L.converged || L.iter >= cfg.max_iterations) {
-            L.done = 1;
-          } else {
-            // the speculative linearisation at xi (== new x0) becomes current
-            adopt_new(L, sums);
-            L.nr_iterations = L.iter;
-            L.nu = 2.0;
-            L.trial = 0;
-            make_trial(L, L.lambda);
-          }
-        }
-      }
       NG_SSTAMP(5);
-      if (gn && !L.done) L.xi = L.x0;  // GN: the next pass linearises at the updated estimate
       if (!L.done) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -926,7 +942,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
             const float f = (float)(c < 3 ? L.xi.R[r * 3 + c] : L.xi.t[r]);
             // (persistent: solvers of different passes sit on different XCDs - a plain store would leave one dirty copy of the word per L2)
             if constexpr (PERSIST) __hip_atomic_store(&st->xi_f[r * 4 + c], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else st->xi_f[r * 4 + c] = f;
+            else sto->xi_f[r * 4 + c] = f;
           }
         }
       }
@@ -972,7 +988,9 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
     }
     __hip_atomic_store(st->view + (size_t)L.passes * kViewWords + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (pass L.passes comes next)
   } else {
-    for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&st->hot)[w] = reinterpret_cast<const int*>(&L)[w];
+    for (int w = lane; w < (int)(sizeof(LmHot) / 4); w += 64) reinterpret_cast<int*>(&sto->hot)[w] = reinterpret_cast<const int*>(&L)[w];
+    // (a state that ends an alignment keeps the float pose of its last pass: k_corr_to_original reads it from wherever the state lies)
+    if (sto != st && L.done && lane < 12) sto->xi_f[lane] = st->xi_f[lane];
   }
   NG_SSTAMP(6);
 #undef NG_SSTAMP
@@ -1125,6 +1143,171 @@ __device__ __forceinline__ void persist_group_body(A& a, const int group, const 
 #define NG_HAVE_LIN have_lin
 #include "ngicp_pass_group.inc"
 #undef NG_HAVE_LIN
+}
+
+// ---- k_gicp_head: ONE launch per iteration, without a grid-wide meeting.  What the solver launch costs an iteration is not its work
+//      (~1.6 us of serial FP64 and one read) but its dispatch and the two kernel boundaries around it (13.6 us of 48 at c3).  Here the
+//      kernel boundary between two passes is the only synchronisation: the blocks of pass i add their rows up per SUBSET of groups
+//      (subset = group index mod 32, the solver's own summation order: the last block of a subset to finish - a ticket per subset,
+//      rows written through, read back with agent-scope loads, no fence - adds its subset's rows in ascending group order), and every
+//      block of launch i + 1 begins by reading the state image and those 32 rows, adds them in subset order and runs the optimiser's
+//      step ITSELF (lm_step, the very function the solver runs; same inputs, same order, so every block arrives at the same pose, and
+//      at the bits the two-launch path arrives at).  Block 0 of every launch is the SOLVER BLOCK: the same step through lm_solve_body,
+//      with everything that leaves the kernel - the advanced state image (into the other of two buffers: the launch's own blocks are
+//      still reading this one), trace rows, the progress word, the final image for the host, the next launch order (into the other
+//      of two order buffers, for the same reason).  One more launch than passes: the head that consumes the last pass's rows. ----
+struct HeadShared {
+  LmHot L;
+  double sums[kPartialStride];
+  double crow[kSolveRowSubsets][kNumSlots + 1];
+};
+__device__ __forceinline__ double uniform_double(double v) {  // (a value every lane holds alike, into scalar registers)
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <int G, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_gicp_head(PassArgs a) {
+  constexpr bool FUSED = true;  // (rows and costs are stored write-through: another block of this launch reads the rows)
+  constexpr int B = 64 / G;
+  constexpr int kWin = WPS >= 4 ? 12 : 16, kSideStep = WPS >= 4 ? 8 : 16;  // (see k_gicp_pass)
+  static_assert(kWin <= kSortedPad && B == kBatchQueries, "see k_gicp_pass");
+  __shared__ double lds[4][kNumSlots];
+  union HeadPassShared {
+    WaveStage stage[4];
+    SolveShared<256> sv;  // the solver block
+    HeadShared hs;        // a search block's head, before its search tables
+  };
+  __shared__ HeadPassShared shm;
+  __shared__ int last_block;
+  // Everything the head needs from memory is requested at once - the done word, the state image, the 32 subset rows - and looked at
+  // afterwards: one round trip instead of three in a row.
+  const unsigned long long t_entry = a.dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  const LmState* __restrict__ st = a.st;
+  const int n_groups = (int)gridDim.x - 1;
+  {
+    HeadShared& H = shm.hs;
+    constexpr int kHotWords = (int)(sizeof(LmHot) / 4);
+    static_assert(kHotWords <= 2 * 256, "two words of the state image per thread");
+    static_assert(kSolveRowSubsets * kNumSlots == 256 * 4, "a thread fetches four doubles of the subset rows");
+    const int done_before = *a.done_flag;  // (an earlier launch has ended the alignment; the host had enqueued this one ahead)
+    const int w0 = threadIdx.x, w1 = threadIdx.x + 256;
+    const int i0 = reinterpret_cast<const int*>(&st->hot)[w0], i1 = w1 < kHotWords ? reinterpret_cast<const int*>(&st->hot)[w1] : 0;
+    const int c = threadIdx.x >> 3, v0 = (threadIdx.x & 7) * 4;
+    const double* src = a.crow_in + c * kNumSlots + v0;
+    const double r0 = src[0], r1 = src[1], r2 = src[2], r3 = src[3];  // (zeros before the first pass)
+    if (done_before) return;
+    reinterpret_cast<int*>(&H.L)[w0] = i0;
+    if (w1 < kHotWords) reinterpret_cast<int*>(&H.L)[w1] = i1;
+    H.crow[c][v0] = r0; H.crow[c][v0 + 1] = r1; H.crow[c][v0 + 2] = r2; H.crow[c][v0 + 3] = r3;
+  }
+  __syncthreads();
+  const bool pending = shm.hs.L.pending != 0;  // (block-uniform)
+  if (blockIdx.x == 0) {
+    // ---- the solver block
+    __syncthreads();  // (lm_solve_body lays its scratch over the head's)
+    if (pending) {
+      lm_solve_body<256, false>(a.sa, shm.sv);  // (a.sa: partials = the 32 subset rows, st_out = the other state buffer)
+      __syncthreads();
+      if (threadIdx.x == 0 && shm.sv.L.done) *a.done_flag = 1;
+    } else {
+      // the first launch of an alignment: nothing to consume yet; the state moves on unchanged, marked as having a pass under way
+      LmState* sto = a.sa.st_out;
+      for (int w = threadIdx.x; w < (int)(sizeof(LmHot) / 4); w += 256) reinterpret_cast<int*>(&sto->hot)[w] = reinterpret_cast<const int*>(&st->hot)[w];
+      if (threadIdx.x < 12) sto->xi_f[threadIdx.x] = st->xi_f[threadIdx.x];
+      __syncthreads();
+      if (threadIdx.x == 0) sto->hot.pending = 1;
+    }
+    return;
+  }
+  // ---- head of a search block: the state this pass runs at.  Wave 0 adds the subset rows (lane v: slot v, subsets in order - the
+  //      solver's own order) and its lane 0 steps the optimiser; the other waves wait at the barrier.
+  if (pending && threadIdx.x < 64) {
+    HeadShared& H = shm.hs;
+    if (threadIdx.x < kPartialStride) {
+      double tsum = 0.0;
+      if (threadIdx.x < kNumSlots)
+        for (int c = 0; c < kSolveRowSubsets; ++c) tsum += H.crow[c][threadIdx.x];
+      H.sums[threadIdx.x] = tsum;
+    }
+    wave_lds_sync();
+    if (threadIdx.x == 0) lm_step(H.L, a.sa.cfg, H.sums, nullptr, 0);  // (no trace row: the solver block writes it)
+  }
+  __syncthreads();
+  if (shm.hs.L.done) return;  // (block-uniform; the solver block tells the host)
+  const int have_lin = __builtin_amdgcn_readfirstlane(shm.hs.L.have_lin);
+  const int cur = __builtin_amdgcn_readfirstlane(shm.hs.L.cur) & 1, nxt = cur ^ 1;
+  double R[9], t[3];
+  float Tf[12];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = uniform_double(shm.hs.L.xi.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = uniform_double(shm.hs.L.xi.t[i]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Tf[r * 4 + c] = (float)R[r * 3 + c];
+    Tf[r * 4 + 3] = (float)t[r];
+  }
+  __syncthreads();  // (the search tables lie where the head's scratch was)
+  const bool do_err = (a.mode & 1) && have_lin;
+  const bool do_lin = (a.mode & 2);
+  const float4* __restrict__ tpt_old = a.tpt[cur];
+  const double* __restrict__ mahal_old = a.mahal[cur];
+  float4* __restrict__ tpt_new = a.tpt[nxt];
+  double* __restrict__ mahal_new = a.mahal[nxt];
+  const Grid& g = a.grid;
+  double wave_total = 0.0;
+  unsigned int ncand = 0, nvalid = 0, nstaged = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % G, grp = lane / G;
+  WaveStage& S = shm.stage[wave];
+  if (a.dbg_stamps && lane == 0) {  // diagnostic only: entry, end of the head
+    unsigned long long* d = a.dbg_stamps + (size_t)(blockIdx.x * 4 + wave) * kStampStride;
+    d[20] = t_entry;
+    d[21] = __builtin_amdgcn_s_memtime();
+  }
+  NG_STAMP(0);
+  const int slot = (int)blockIdx.x - 1;
+  const int group = (a.grp_order && a.order_valid && *a.order_valid) ? a.grp_order[slot] : slot;
+  const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (a.t_first && slot == 0 && threadIdx.x == 0 && !have_lin) *a.t_first = __builtin_amdgcn_s_memrealtime();
+#define NG_HAVE_LIN have_lin
+#include "ngicp_pass_group.inc"
+#undef NG_HAVE_LIN
+  // ---- tail: the last block of the group's subset adds the subset's rows
+  const int c = group % kSolveRowSubsets;
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const int members = (n_groups - c + kSolveRowSubsets - 1) / kSolveRowSubsets;
+      const int tk = __hip_atomic_fetch_add(a.cluster_ticket + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_block = (tk == members - 1) ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * kStampStride + 22] = __builtin_amdgcn_s_memtime();  // (ticket drawn)
+  if (!last_block || wave != 0) return;
+  if (lane < kNumSlots) {
+    // rows c, c + 32, c + 64, ... in ascending order, sixteen loads in flight at a time; rows beyond the grid add 0.0 (as the solver does)
+    constexpr int kChunk = 16;
+    const double* rows = a.partials + lane;
+    double acc = 0.0;
+    for (int g0 = c; g0 < n_groups; g0 += kSolveRowSubsets * kChunk) {
+      double v[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const int gi = g0 + j * kSolveRowSubsets;
+        v[j] = gi < n_groups ? __hip_atomic_load(rows + (size_t)gi * kNumSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+      if (g0 == c) acc = v[0]; else acc += v[0];
+#pragma unroll
+      for (int j = 1; j < kChunk; ++j) acc += v[j];
+    }
+    a.crow_out[c * kNumSlots + lane] = acc;
+  }
+  if (lane == 0) __hip_atomic_store(a.cluster_ticket + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch: ordered by the kernel boundary)
+  if (a.dbg_stamps && lane == 0) a.dbg_stamps[(size_t)(blockIdx.x * 4 + wave) * kStampStride + 23] = __builtin_amdgcn_s_memtime();  // (subset row stored)
 }
 
 // ---- the persistent kernel: ONE launch per alignment.  A thin loop over passes and over the block's groups around two CALLED functions

@@ -467,18 +467,21 @@ def test_full_size_properties(ng):
         assert np.allclose(tr[:, 4], runs[0][1][:, 4], atol=1e-2)
 
 
+@pytest.mark.parametrize("switch", ["NGICP_PERSIST", "NGICP_HEAD"])
 @pytest.mark.parametrize("case", ["dlo_s2s", "fixed20", "gauss_newton", "one_iteration"])
-def test_persistent_kernel_equals_one_launch_per_pass(ng, monkeypatch, case):
-    """NGICP_PERSIST=1 (ONE launch per alignment: the blocks keep their groups, meet after every pass, the last one steps the optimiser)
-    against the default (one pass launch + one solver launch per iteration): the same sums in the same order, so everything is
-    bit-identical - pose, Hessian, trace, correspondences.  A 100k-point source has more groups (866) than the persistent grid has
-    blocks (768): some blocks take two groups per pass; 10k points leave most of the grid's blocks without a group of their own."""
+def test_persistent_kernel_equals_one_launch_per_pass(ng, monkeypatch, case, switch):
+    """The two ways of running an iteration without a solver launch, against the default (one pass launch + one solver launch per
+    iteration).  NGICP_PERSIST=1: ONE launch per alignment - the blocks keep their groups, meet after every pass, the last one steps the
+    optimiser.  NGICP_HEAD=1: one launch per iteration - the blocks add their rows up per subset, and every block of the next launch steps
+    the optimiser itself at its head.  The same sums in the same order, so everything is bit-identical - pose, Hessian, trace,
+    correspondences.  A 100k-point source has more groups (866) than the persistent grid has blocks (768): some blocks take two groups
+    per pass; 10k points leave most of the grid's blocks without a group of their own."""
     for w in (clouds.scan_to_scan(10_000), clouds.scan_to_submap(100_000, 5)):
         if len(w.source) > 50_000 and case not in ("fixed20", "one_iteration"):
             continue
         out = []
         for persist in ("0", "1"):
-            monkeypatch.setenv("NGICP_PERSIST", persist)  # (read when the handle is created)
+            monkeypatch.setenv(switch, persist)  # (read when the handle is created)
             g = ng.NanoGICP(); g.setMaxCorrespondenceDistance(w.max_corr_dist)
             for k, v in CASES[case].items():
                 getattr(g, k)(v)
@@ -489,7 +492,7 @@ def test_persistent_kernel_equals_one_launch_per_pass(ng, monkeypatch, case):
                 runs.append((g.getFinalTransformation().copy(), g.getFinalHessian().copy(), g.lm_trace().copy(), g.nr_iterations_, g.converged_, g.stats()["passes"]))
             corr = g.correspondences()
             out.append((runs, corr))
-        monkeypatch.delenv("NGICP_PERSIST")
+        monkeypatch.delenv(switch)
         for (a, b) in zip(out[0][0], out[1][0]):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:] == b[3:]
         assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
