@@ -103,6 +103,8 @@ struct DeviceCloud {
   DevBuf cell_start;  // int[kCellPad + ncells + 1 + kCellPad]: the exclusive prefix of points per cell, framed by kCellPad entries on each side (0 in
                       // front, n behind) so that the pass may fetch the four bounds around a cell with ONE 16-byte load at any cell
   int* cells() const { return cell_start.as<int>() + kCellPad; }
+  DevBuf cell_box;    // uint[kCellPad + ncells + kCellPad]: the (y,z) extent of every cell's points inside the cell (k_cell_boxes), framed by
+                      // empty boxes
   DevBuf qpts;        // float4[n]  the points in Morton-tile query order, w = sorted position
   DevBuf batches;     // int2[n_batches] {first qpts index, count <= 32}: tile-aligned query batches
   DevBuf n_batches_dev;
@@ -361,6 +363,16 @@ int pick_blocks(size_t work_items, int per_block, int max_blocks) {
 // ------------------------------------------------------------------------------------------
 // Index build
 // ------------------------------------------------------------------------------------------
+// NGICP_CELL_BOXES=1 (experiment, round 3): per-cell (y,z) extents of the points, built with every index; the pass cuts and prunes its
+// ring-1 (query, row) pairs with them.  Exact, a quarter fewer candidates (c3 68.4 -> 52.2 per query, c5 25.9 -> 23.8), 25 % fewer
+// ring-1 units per wave - and the launch exactly as long as before (c3 33.7 us either way, c5 41.3 -> 42.5: the second load per row):
+// the units it removes were served in parallel by lanes that would otherwise idle.  Off by default.
+bool cell_boxes_on() {
+  static const bool on = std::getenv("NGICP_CELL_BOXES") && std::atoi(std::getenv("NGICP_CELL_BOXES")) != 0;
+  return on;
+}
+const unsigned int* boxes_of(const DeviceCloud& dc) { return cell_boxes_on() ? dc.cell_box.as<unsigned int>() + kCellPad : nullptr; }
+
 Grid make_grid(const float mn[3], const float mx[3], double h, int max_cells) {
   Grid g{};
   double ext[3];
@@ -504,6 +516,11 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
                      h->tmp.as<float4>());
   hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cells(), dc->pts(),
                      dc->perm.as<int>());
+  if (cell_boxes_on()) {
+  dc->cell_box.ensure((size_t)(g.ncells + 2 * kCellPad) * sizeof(unsigned int));
+  hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(2 * kCellPad), 0, h->stream, dc->cell_box.as<unsigned int>(), dc->cell_box.as<unsigned int>() + kCellPad + g.ncells, kCellPad, kCellBoxEmpty);
+  hipLaunchKernelGGL(k_cell_boxes, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, h->stream, dc->pts(), dc->cells(), g, dc->cell_box.as<unsigned int>() + kCellPad);
+  }
   dc->sorted3.ensure((n + 2 * kSortedPad) * sizeof(Xyz));
   hipLaunchKernelGGL(k_pack_xyz, dim3((unsigned)((n + 2 * kSortedPad + 255) / 256)), dim3(256), 0, h->stream, dc->sorted.as<float4>(), ni + 2 * kSortedPad, dc->sorted3.as<Xyz>());
   dc->sortedp.ensure((n + 2 * kSortedPad) * sizeof(float4));
@@ -778,6 +795,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.tgt3 = T.xyz3();
   a.tgtp = T.xyzp();
   a.tgt_cell_start = T.cells();
+  a.tgt_cell_box = boxes_of(T);
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
   for (int i = 0; i < 2; ++i) {

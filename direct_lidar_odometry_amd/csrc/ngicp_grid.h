@@ -64,6 +64,63 @@ __device__ __forceinline__ float row_gap_sq(const Grid& g, int ry, int rz, int c
   return gy * gy + gz * gz;
 }
 
+// --- per-cell (y,z) extents ---------------------------------------------------------------------
+// A cell's points usually fill a small part of its (y,z) square: a scan line, a wall seen along x, the ground.  One 32-bit word per
+// cell holds their extent inside the cell, y and z, in 1/255 of the cell edge, rounded outwards: {y lo, y hi, z lo, z hi}, a byte each;
+// an empty cell has lo = 255 > hi = 0.  A query's distance to what a run of cells really holds - instead of to their squares - drops
+// (query, row) pairs without a memory access and, above all, shortens the walks along structures parallel to x: the x-reach of a walk is
+// sqrt(bound - gap), and the squares' gap is up to a cell edge short of the true one.
+constexpr unsigned int kCellBoxEmpty = 0x00ff00ffu;
+__device__ __forceinline__ unsigned int cell_box_union(unsigned int a, unsigned int b) {  // (an empty box is the neutral element)
+  const unsigned int ylo = min(a & 0xffu, b & 0xffu), yhi = max((a >> 8) & 0xffu, (b >> 8) & 0xffu);
+  const unsigned int zlo = min((a >> 16) & 0xffu, (b >> 16) & 0xffu), zhi = max(a >> 24, b >> 24);
+  return ylo | (yhi << 8) | (zlo << 16) | (zhi << 24);
+}
+// lower bound of the squared (y,z) distance from (qy, qz) to any point of the cells of grid row (ry, rz) whose boxes were united in `box`
+// (same slack as row_gap_sq: a point may sit a rounding error outside the cell it was assigned to); 3.4e38 for an empty box
+__device__ __forceinline__ float box_gap_sq(const Grid& g, int ry, int rz, unsigned int box, float qy, float qz) {
+  const float ylo = (float)(box & 0xffu), yhi = (float)((box >> 8) & 0xffu), zlo = (float)((box >> 16) & 0xffu), zhi = (float)(box >> 24);
+  if (ylo > yhi) return 3.4028234664e38f;
+  const float s = g.h * (1.0f / 255.0f);
+  const float y0 = g.oy + (float)ry * g.h, z0 = g.oz + (float)rz * g.h;
+  float gy = fmaxf(fmaxf((y0 + ylo * s) - qy, qy - (y0 + yhi * s)), 0.f);
+  float gz = fmaxf(fmaxf((z0 + zlo * s) - qz, qz - (z0 + zhi * s)), 0.f);
+  gy = fmaxf(gy - g.slack, 0.f);
+  gz = fmaxf(gz - g.slack, 0.f);
+  return gy * gy + gz * gz;
+}
+__global__ void k_fill_u32(unsigned int* a, unsigned int* b, int n, unsigned int v) {  // the frame of a padded table: n entries at a, n at b
+  const int t = threadIdx.x;
+  if (t < n) a[t] = v; else if (t < 2 * n) b[t - n] = v;
+}
+// one thread per cell over the cell-sorted points (cells with more than kCellBoxScan points keep the whole square: bounded time)
+constexpr int kCellBoxScan = 512;
+__global__ void __launch_bounds__(256) k_cell_boxes(const float4* __restrict__ pts, const int* __restrict__ cell_start, Grid g, unsigned int* __restrict__ box) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.ncells) return;
+  const int s = cell_start[c], e = cell_start[c + 1];
+  unsigned int out = kCellBoxEmpty;
+  if (e > s) {
+    out = 0xff00ff00u;  // the whole square
+    if (e - s <= kCellBoxScan) {
+      const int cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+      const float y0 = g.oy + (float)cy * g.h, z0 = g.oz + (float)cz * g.h;
+      float ymin = 3.0e38f, ymax = -3.0e38f, zmin = 3.0e38f, zmax = -3.0e38f;
+      for (int i = s; i < e; ++i) {
+        const float4 p = pts[i];
+        ymin = fminf(ymin, p.y); ymax = fmaxf(ymax, p.y);
+        zmin = fminf(zmin, p.z); zmax = fmaxf(zmax, p.z);
+      }
+      // outwards, with one unit to spare for the float arithmetic on either side of the encoding
+      const float k = 255.0f * g.inv_h;
+      const int ylo = max(0, min(255, (int)floorf((ymin - y0) * k) - 1)), yhi = max(0, min(255, (int)ceilf((ymax - y0) * k) + 1));
+      const int zlo = max(0, min(255, (int)floorf((zmin - z0) * k) - 1)), zhi = max(0, min(255, (int)ceilf((zmax - z0) * k) + 1));
+      out = (unsigned int)ylo | ((unsigned int)yhi << 8) | ((unsigned int)zlo << 16) | ((unsigned int)zhi << 24);
+    }
+  }
+  box[c] = out;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Build kernels
 // ---------------------------------------------------------------------------------------------

@@ -155,6 +155,7 @@ struct PassArgs {
   const Xyz* tgt3;          // the same points packed 12 bytes each (same sentinel frame): what the walks and the tail fetch - a quarter
                             // fewer bytes per candidate and three registers per point instead of four
   const int* tgt_cell_start;
+  const unsigned int* tgt_cell_box;  // per-cell (y,z) extents of the target's points (k_cell_boxes; framed like the cell-start table), or null
   const double* cov_tgt;    // [n_tgt][6], target sorted order
   Grid grid;                // target grid
   float4* tpt[2];           // [n_src] the correspondence of each query: {x, y, z of the target point, bitcast(sorted target position or -1)}:

@@ -41,7 +41,7 @@ m = (a[:, 16] > 0) & (a[:, 17] > 0)
 for name, d in (("ring1: bounds + enqueue", a[m, 16] - a[m, 3]), ("ring1: drain queue", a[m, 17] - a[m, 16]), ("ring1: final sync", a[m, 4] - a[m, 17])):
     print(f"{name:26s} p10/p50/p90/max: {np.percentile(d,10):9.0f} {np.percentile(d,50):9.0f} {np.percentile(d,90):9.0f} {d.max():9.0f}")
 print("units per wave p50/p90/max:", np.percentile(a[m, 19], [50, 90, 100]), " max units popped by one lane p50/p90/max:", np.percentile(a[m, 18], [50, 90, 100]))
-x15 = raw[m, 15]; steps = (x15 >> np.uint64(48)).astype(int)
+x15 = raw[raw[:, 0] > 0][m, 15]; steps = (x15 >> np.uint64(48)).astype(int)
 drain = a[m, 17] - a[m, 16]
 A = np.vstack([np.ones_like(steps), steps]).T; coef = np.linalg.lstsq(A, drain, rcond=None)[0]
 print("drain ~ %.0f + %.0f * (max-lane window steps)" % tuple(coef), " corr", np.corrcoef(drain, steps)[0, 1])
