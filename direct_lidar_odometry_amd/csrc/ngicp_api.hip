@@ -104,7 +104,8 @@ struct DeviceCloud {
                       // front, n behind) so that the pass may fetch the four bounds around a cell with ONE 16-byte load at any cell
   int* cells() const { return cell_start.as<int>() + kCellPad; }
   DevBuf cell_box;    // uint[kCellPad + ncells + kCellPad]: the (y,z) extent of every cell's points inside the cell (k_cell_boxes), framed by
-                      // empty boxes
+                      // empty boxes; only when the building handle had NGICP_CELL_BOXES on
+  bool has_boxes = false;
   DevBuf qpts;        // float4[n]  the points in Morton-tile query order, w = sorted position
   DevBuf batches;     // int2[n_batches] {first qpts index, count <= 32}: tile-aligned query batches
   DevBuf n_batches_dev;
@@ -291,6 +292,7 @@ struct ngicp {
   int order_sel = 0;     // which of the two launch-order buffers (and flag words) the next alignment reads
   DevBuf grp_order_alt;  // the second order buffer: the persistent kernel's solver builds the NEXT alignment's order there
   DevBuf gen_lines;      // the persistent kernel's release word, kGenLines copies (PassArgs::gen)
+  int cell_boxes = 0;    // env NGICP_CELL_BOXES=1: per-cell (y,z) extents built with every index and used by the pass (see "Index build")
   int head = 0;          // env NGICP_HEAD=1: k_gicp_head - no solver launch, every block steps the optimiser at its head
   DevBuf state_alt;      // k_gicp_head: the second state buffer (a launch's solver block writes the one its blocks are not reading)
   DevBuf head_ws;        // k_gicp_head: {done flag (64 B), subset tickets (128 B), subset rows of even / odd launches (2 x 8 KB)}
@@ -367,11 +369,7 @@ int pick_blocks(size_t work_items, int per_block, int max_blocks) {
 // ring-1 (query, row) pairs with them.  Exact, a quarter fewer candidates (c3 68.4 -> 52.2 per query, c5 25.9 -> 23.8), 25 % fewer
 // ring-1 units per wave - and the launch exactly as long as before (c3 33.7 us either way, c5 41.3 -> 42.5: the second load per row):
 // the units it removes were served in parallel by lanes that would otherwise idle.  Off by default.
-bool cell_boxes_on() {
-  static const bool on = std::getenv("NGICP_CELL_BOXES") && std::atoi(std::getenv("NGICP_CELL_BOXES")) != 0;
-  return on;
-}
-const unsigned int* boxes_of(const DeviceCloud& dc) { return cell_boxes_on() ? dc.cell_box.as<unsigned int>() + kCellPad : nullptr; }
+// (read at ngicp_create: ngicp::cell_boxes; an index carries boxes when the handle that built it had the switch on)
 
 Grid make_grid(const float mn[3], const float mx[3], double h, int max_cells) {
   Grid g{};
@@ -516,7 +514,8 @@ std::shared_ptr<DeviceCloud> index_unsorted(ngicp* h, size_t n, const float mn[3
                      h->tmp.as<float4>());
   hipLaunchKernelGGL(k_cell_rank, dim3(pick_blocks(n, 256, 4096)), dim3(256), 0, h->stream, h->tmp.as<float4>(), ni, g, dc->cells(), dc->pts(),
                      dc->perm.as<int>());
-  if (cell_boxes_on()) {
+  dc->has_boxes = h->cell_boxes != 0;
+  if (dc->has_boxes) {
   dc->cell_box.ensure((size_t)(g.ncells + 2 * kCellPad) * sizeof(unsigned int));
   hipLaunchKernelGGL(k_fill_u32, dim3(1), dim3(2 * kCellPad), 0, h->stream, dc->cell_box.as<unsigned int>(), dc->cell_box.as<unsigned int>() + kCellPad + g.ncells, kCellPad, kCellBoxEmpty);
   hipLaunchKernelGGL(k_cell_boxes, dim3((unsigned)((g.ncells + 255) / 256)), dim3(256), 0, h->stream, dc->pts(), dc->cells(), g, dc->cell_box.as<unsigned int>() + kCellPad);
@@ -795,7 +794,7 @@ void prepare_loop(ngicp* h, LoopCtx& c) {
   a.tgt3 = T.xyz3();
   a.tgtp = T.xyzp();
   a.tgt_cell_start = T.cells();
-  a.tgt_cell_box = boxes_of(T);
+  a.tgt_cell_box = (h->cell_boxes && T.has_boxes) ? T.cell_box.as<unsigned int>() + kCellPad : nullptr;
   a.cov_tgt = covs_for(h, h->tgt_covs, h->tgt.dev);
   a.grid = T.grid;
   for (int i = 0; i < 2; ++i) {
@@ -1437,6 +1436,7 @@ int ngicp_create(int device, ngicp_t** out) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_ticks), 2 * kMaxTickPasses * sizeof(unsigned long long), hipHostMallocDefault));
     if (const char* s = std::getenv("NGICP_PERSIST")) h->persist = std::atoi(s);
     if (const char* s = std::getenv("NGICP_HEAD")) h->head = std::atoi(s);
+    if (const char* s = std::getenv("NGICP_CELL_BOXES")) h->cell_boxes = std::atoi(s);
     if (const char* s = std::getenv("NGICP_TARGET_OCC")) h->target_occupancy = std::max(1.0, std::atof(s));
     if (const char* s = std::getenv("NGICP_VOXEL")) h->voxel_size = std::atof(s);
     if (const char* s = std::getenv("NGICP_CHUNK")) h->chunk_pairs = std::max(1, std::min(64, std::atoi(s)));

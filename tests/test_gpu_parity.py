@@ -467,7 +467,7 @@ def test_full_size_properties(ng):
         assert np.allclose(tr[:, 4], runs[0][1][:, 4], atol=1e-2)
 
 
-@pytest.mark.parametrize("switch", ["NGICP_PERSIST", "NGICP_HEAD"])
+@pytest.mark.parametrize("switch", ["NGICP_PERSIST", "NGICP_HEAD", "NGICP_CELL_BOXES"])
 @pytest.mark.parametrize("case", ["dlo_s2s", "fixed20", "gauss_newton", "one_iteration"])
 def test_persistent_kernel_equals_one_launch_per_pass(ng, monkeypatch, case, switch):
     """The two ways of running an iteration without a solver launch, against the default (one pass launch + one solver launch per
@@ -475,7 +475,8 @@ def test_persistent_kernel_equals_one_launch_per_pass(ng, monkeypatch, case, swi
     optimiser.  NGICP_HEAD=1: one launch per iteration - the blocks add their rows up per subset, and every block of the next launch steps
     the optimiser itself at its head.  The same sums in the same order, so everything is bit-identical - pose, Hessian, trace,
     correspondences.  A 100k-point source has more groups (866) than the persistent grid has blocks (768): some blocks take two groups
-    per pass; 10k points leave most of the grid's blocks without a group of their own."""
+    per pass; 10k points leave most of the grid's blocks without a group of their own.  NGICP_CELL_BOXES=1 (per-cell (y,z) extents that
+    cut and prune the ring-1 pairs) rides along: an exact search finds the same neighbours, so it is bit-identical too."""
     for w in (clouds.scan_to_scan(10_000), clouds.scan_to_submap(100_000, 5)):
         if len(w.source) > 50_000 and case not in ("fixed20", "one_iteration"):
             continue
