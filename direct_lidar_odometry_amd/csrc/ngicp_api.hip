@@ -287,6 +287,7 @@ struct ngicp {
   DevBuf raw, unsorted, keys, counts, fill, tile_sums, tile_sq, tmp, bbox, occ;
   int pass_slots = 768;  // blocks of the 3-waves-per-SIMD pass kernel resident on this device at once
   int persist_slots = 0; // blocks of the persistent pass kernel resident at once (its grid), 0: not available
+  int queue_slots[2] = {768, 1024};  // blocks of k_gicp_queue<2, 3> / <2, 4> resident at once
   int persist = 0;       // env NGICP_PERSIST=1: ONE launch per alignment (k_gicp_persist).  Exact and complete, but measured no faster than one
                          // launch per pass: off by default
   int order_sel = 0;     // which of the two launch-order buffers (and flag words) the next alignment reads
@@ -730,6 +731,15 @@ void launch_pass(ngicp* h, const PassArgs& a, int nblocks, hipStream_t s, hipEve
       hipExtLaunchKernelGGL((k_gicp_pass_st<4>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, b);
     else
       hipExtLaunchKernelGGL((k_gicp_pass_st<3>), dim3(nblocks), dim3(256), 0, s, start, stop, 0, b);
+    return;
+  }
+  // NGICP_QUEUE=1 (experiment, round 3): a grid of resident blocks that draw their groups from a counter (k_gicp_queue)
+  static const int queue_env = std::getenv("NGICP_QUEUE") ? std::atoi(std::getenv("NGICP_QUEUE")) : 0;
+  if (queue_env && !a.fused && !(a.mode & 4) && !a.dbg_stamps && !a.dbg_span && !a.dbg_qstats) {
+    if (four)
+      hipExtLaunchKernelGGL((k_gicp_queue<2, 4>), dim3((unsigned)std::min(nblocks, h->queue_slots[1])), dim3(256), 0, s, start, stop, 0, a);
+    else
+      hipExtLaunchKernelGGL((k_gicp_queue<2, 3>), dim3((unsigned)std::min(nblocks, h->queue_slots[0])), dim3(256), 0, s, start, stop, 0, a);
     return;
   }
   if (a.fused) {  // (the solver in the tail of the launch: a build of its own)
@@ -1430,6 +1440,9 @@ int ngicp_create(int device, ngicp_t** out) {
       h->pass_slots = std::max(1, cus) * std::max(1, per_cu);
       int per_cu_p = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_p, k_gicp_persist<2, 3>, 256, 0) == hipSuccess) h->persist_slots = std::max(0, cus) * std::max(0, per_cu_p);
+      int q3 = 0, q4 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q3, k_gicp_queue<2, 3>, 256, 0) == hipSuccess && q3 > 0) h->queue_slots[0] = cus * q3;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q4, k_gicp_queue<2, 4>, 256, 0) == hipSuccess && q4 > 0) h->queue_slots[1] = cus * q4;
       int coop = 0;
       if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) h->persist_slots = 0;
     }

@@ -1102,9 +1102,11 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
 // kernel's loops, everything the loops keep alive pushed the search's registers into scratch memory - 2.5x the time per pass).  The
 // arguments are read where the hardware put them, through the constant address space (a.field is then a scalar load the compiler may
 // repeat instead of keeping the value, exactly as in a kernel of its own); the trial pose comes from entry pass_no of the ring of views.
-template <int G, int WPS, class A>
+// RING false (k_gicp_queue, one launch per pass): the pose comes from the state itself, which does not change while the launch runs, and
+// the block's row is stored plainly - the solver launch reads it behind a kernel boundary.
+template <int G, int WPS, bool RING, class A>
 __device__ __forceinline__ void persist_group_body(A& a, const int group, const int pass_no, WaveStage* stage_all, double (*lds)[kNumSlots]) {
-  constexpr bool FUSED = true;  // (the block's row and cost are stored write-through)
+  constexpr bool FUSED = RING;  // (persistent: the block's row and cost are stored write-through)
   constexpr int B = 64 / G;
   constexpr int kWin = WPS >= 4 ? 12 : 16, kSideStep = WPS >= 4 ? 8 : 16;  // (see k_gicp_pass)
   static_assert(kWin <= kSortedPad && B == kBatchQueries, "see k_gicp_pass");
@@ -1119,11 +1121,13 @@ __device__ __forceinline__ void persist_group_body(A& a, const int group, const 
   typedef const int __attribute__((address_space(4))) * ViewPtr;
   typedef const double __attribute__((address_space(4))) * ViewPtrD;
   typedef const float __attribute__((address_space(4))) * ViewPtrF;
+  typedef const LmState __attribute__((address_space(4))) * StatePtr;
+  StatePtr st4 = (StatePtr)(unsigned long long)a.st;
   ViewPtr vw = (ViewPtr)(unsigned long long)(a.st->view + (size_t)(a.first_pass + pass_no) * kViewWords);
-  const int have_lin = vw[kViewHaveLin];
-  const int cur = vw[kViewCur] & 1, nxt = cur ^ 1;  // (indices into two-element arrays of pointers, whatever the memory holds)
-  ViewPtrD vx = (ViewPtrD)(vw + kViewXi);
-  ViewPtrF vf = (ViewPtrF)(vw + kViewXiF);
+  const int have_lin = RING ? vw[kViewHaveLin] : st4->hot.have_lin;
+  const int cur = (RING ? vw[kViewCur] : st4->hot.cur) & 1, nxt = cur ^ 1;  // (indices into two-element arrays of pointers, whatever the memory holds)
+  ViewPtrD vx = RING ? (ViewPtrD)(vw + kViewXi) : (ViewPtrD)&st4->hot.xi;  // (Pose: R[9] then t[3], as in the view)
+  ViewPtrF vf = RING ? (ViewPtrF)(vw + kViewXiF) : (ViewPtrF)st4->xi_f;
   double R[9], t[3];
   float Tf[12];
 #pragma unroll
@@ -1338,12 +1342,46 @@ __device__ __forceinline__ KernelPassArgs* uniform_args(KernelPassArgs* ka) {
 }
 template <int G, int WPS>
 __device__ __attribute__((noinline)) void persist_group_call(KernelPassArgs* ka, int group, int pass_no) {
-  persist_group_body<G, WPS>(*uniform_args(ka), __builtin_amdgcn_readfirstlane(group), __builtin_amdgcn_readfirstlane(pass_no), g_persist_shm.stage, g_persist_lds);
+  persist_group_body<G, WPS, true>(*uniform_args(ka), __builtin_amdgcn_readfirstlane(group), __builtin_amdgcn_readfirstlane(pass_no), g_persist_shm.stage, g_persist_lds);
 }
 
 __device__ __attribute__((noinline)) void persist_solve_call(KernelPassArgs* ka) {
   const char* kargs = (const char*)uniform_args(ka);
   lm_solve_body<256, true, true>(*reinterpret_cast<const SolveArgs*>(kargs + offsetof(PassArgs, sa)), g_persist_shm.sv);
+}
+
+// ---- k_gicp_queue: one launch per pass, as k_gicp_pass, but a grid of as many blocks as are RESIDENT together, each drawing its next
+//      group from a counter (launch order = the order of the draws: heaviest first as before) instead of leaving a freed slot to the
+//      dispatcher, which does not refill it at once (c5, 2217 groups over 1024 slots: the slots 15-20 % empty between rounds).  No
+//      block waits for another; the solver is a launch of its own as ever. ----
+template <int G, int WPS>
+__device__ __attribute__((noinline)) void queue_group_call(KernelPassArgs* ka, int group) {
+  persist_group_body<G, WPS, false>(*uniform_args(ka), __builtin_amdgcn_readfirstlane(group), 0, g_persist_shm.stage, g_persist_lds);
+}
+
+template <int G, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_gicp_queue(PassArgs a) {
+  if (!(a.mode & 4) && a.st->hot.done) return;
+  KernelPassArgs* ka = (KernelPassArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  const bool ordered = a.grp_order && a.order_valid && *a.order_valid;
+  const int n_groups = (a.n_batches + 3) / 4;
+  // The first group of a block is the one of its own number (a thousand blocks drawing from ONE word at the same moment queue up at the
+  // memory channel that holds it: measured +10 us per pass at c3, +28 at c5); from then on position gridDim.x + draw.
+  int slot = (int)blockIdx.x;
+  for (;;) {
+    if (a.t_first && slot == 0 && threadIdx.x == 0 && !a.st->hot.have_lin) *a.t_first = __builtin_amdgcn_s_memrealtime();
+    queue_group_call<G, WPS>(ka, ordered ? a.grp_order[slot] : slot);
+    if (threadIdx.x == 0) g_persist_last = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int draw = g_persist_last;
+    __syncthreads();  // (the word is written again in the next turn; the group's row of sums in LDS has been read)
+    slot = (int)gridDim.x + draw;
+    if (slot >= n_groups) {
+      // every block draws exactly one number beyond the groups - n_groups draws in all; the last puts the counter back for the next launch
+      if (draw == n_groups - 1 && threadIdx.x == 0) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
 }
 
 template <int G, int WPS>

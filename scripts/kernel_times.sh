@@ -17,7 +17,7 @@ d={}
 for r in csv.DictReader(open(f)):
     d.setdefault(r['Kernel_Name'][:40],[]).append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
 for k,v in d.items():
-    if 'gicp_pass' in k:
+    if 'gicp_pass' in k or 'gicp_queue' in k:
         w=[x for x in v if x>15]; print('   pass', round(sum(w)/len(w),2), len(w))
         n=len(w)//4
         if n: print('   pass by position in the align (last align):', [round(x,1) for x in w[-n:]])
