@@ -1032,17 +1032,15 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   __shared__ int last_block;
   WaveStage* stage_all = shm.stage;
   const LmState* __restrict__ st = a.st;
-  if (!(a.mode & 4) && st->hot.done) return;
-
-  const bool do_err = (a.mode & 1) && st->hot.have_lin;
-  const bool do_lin = (a.mode & 2);
+  // Everything a block needs before it can fetch a point - the done flag, the launch-order flag, its position's group - is requested in
+  // ONE go, as scalar loads through the constant address space (none of it changes while the launch runs): the compiler had made six
+  // dependent round trips of it (done -> have_lin -> cur -> pose -> order flag -> order entry, the last two as vector loads), ~4 us on
+  // every block's path before its first point.
+  typedef const int __attribute__((address_space(4))) * ConstIntPtr;
+  const int done_now = st->hot.done, have_lin_now = st->hot.have_lin;
   const int cur = st->hot.cur, nxt = cur ^ 1;
-  const float4* __restrict__ tpt_old = a.tpt[cur];
-  const double* __restrict__ mahal_old = a.mahal[cur];
-  float4* __restrict__ tpt_new = a.tpt[nxt];
-  double* __restrict__ mahal_new = a.mahal[nxt];
-  const Grid& g = a.grid;
-
+  const int order_is_valid = *(ConstIntPtr)(unsigned long long)a.order_valid;             // (both pointers are set for every launch: prepare_loop)
+  const int order_entry = ((ConstIntPtr)(unsigned long long)a.grp_order)[blockIdx.x];    // (read whether valid or not: the buffer exists)
   // trial pose (FP64) and its float cast
   double R[9], t[3];
 #pragma unroll
@@ -1052,11 +1050,22 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   float Tf[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) Tf[i] = st->xi_f[i];
+  // (all of the above is in flight before the first of it is looked at)
+  asm volatile("" ::"s"(done_now), "s"(have_lin_now), "s"(cur), "s"(order_is_valid), "s"(order_entry), "s"(Tf[0]), "s"(Tf[11]), "s"(R[0]), "s"(t[2]));
+  if (!(a.mode & 4) && done_now) return;
+
+  const bool do_err = (a.mode & 1) && have_lin_now;
+  const bool do_lin = (a.mode & 2);
+  const float4* __restrict__ tpt_old = a.tpt[cur];
+  const double* __restrict__ mahal_old = a.mahal[cur];
+  float4* __restrict__ tpt_new = a.tpt[nxt];
+  double* __restrict__ mahal_new = a.mahal[nxt];
+  const Grid& g = a.grid;
 
   double wave_total = 0.0;  // lane v (< 29) accumulates slot v of this wave over its batches
   unsigned int ncand = 0, nvalid = 0, nstaged = 0;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (the wave's number in a scalar register: its batch record is then a scalar load)
   const int sub = lane % G, grp = lane / G;
   WaveStage& S = stage_all[wave];
   NG_STAMP(0);
@@ -1064,11 +1073,11 @@ __global__ void __launch_bounds__(256, WPS) k_gicp_pass(PassArgs a) {
   // index, so the result does not depend on the order in which groups are launched.  That order is the solver's business:
   // it sorts the groups by the duration measured in the previous pass, heaviest first (the grid is ~1.7 waves of blocks
   // deep, and the slowest groups take 2-3x the median: started late they would set the kernel's length).
-  const int group = (a.grp_order && a.order_valid && *a.order_valid) ? a.grp_order[blockIdx.x] : (int)blockIdx.x;
+  const int group = order_is_valid ? order_entry : (int)blockIdx.x;
   const unsigned long long t_start = a.grp_cost ? __builtin_amdgcn_s_memtime() : 0ull;
   if (a.dbg_span && threadIdx.x == 0) a.dbg_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();  // (the 100 MHz counter: the same on every CU)
-  if (a.t_first && blockIdx.x == 0 && threadIdx.x == 0 && !st->hot.have_lin) *a.t_first = __builtin_amdgcn_s_memrealtime();
-#define NG_HAVE_LIN st->hot.have_lin
+  if (a.t_first && blockIdx.x == 0 && threadIdx.x == 0 && !have_lin_now) *a.t_first = __builtin_amdgcn_s_memrealtime();
+#define NG_HAVE_LIN have_lin_now
 #include "ngicp_pass_group.inc"
 #undef NG_HAVE_LIN
   if constexpr (FUSED) {
