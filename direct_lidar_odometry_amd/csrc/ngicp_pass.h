@@ -250,6 +250,9 @@ constexpr int kStageMaxGrow = 6;
 #define NGICP_WALK_WINDOW 12
 #endif
 
+#ifndef NGICP_WALK_PREFETCH
+#define NGICP_WALK_PREFETCH 0  // (measured: c3 32.8 -> 35.8 us, c5 39.2 -> 41.2: the extra requests cost more than the warm lines save) 0: none; 1: the adjacent point of the next window(s); 2: their far end (scan_global_outward)
+#endif
 #ifndef NGICP_PRE_FAR
 #define NGICP_PRE_FAR 0  // (measured: exact, no faster - c3 34.1 vs 33.7 us, c5 43.1 vs 41.3) listed rows queued together with the ring-1 units when the warm start says they will be needed (ngicp_pass_group.inc)
 #endif
@@ -338,6 +341,14 @@ __device__ __forceinline__ void scan_global_outward(const PT* __restrict__ tgt, 
       for (int j = 0; j < W; ++j)
         if (j < kStep || wn == W) c[j] = q[j];
     }
+    // Software prefetch: one word of the window(s) the walk would read NEXT (after the first window: the one on either side; later: the
+    // next in the walk's direction), requested together with this window and looked at only after it has been worked on.  Four in ten
+    // walks go on to a second window, and a step whose line is already in the L2 is a third of a step that goes out to memory.
+    unsigned int pf = 0;
+    if constexpr (NGICP_WALK_PREFETCH != 0) {
+      if (dir >= 0 && hi < e) pf ^= *reinterpret_cast<const unsigned int*>(tgt + (hi + (NGICP_WALK_PREFETCH > 1 ? kStep - 1 : 0)));
+      if (dir <= 0 && lo > s) pf ^= *reinterpret_cast<const unsigned int*>(tgt + (lo - (NGICP_WALK_PREFETCH > 1 ? kStep : 1)));
+    }
     float lb = sqdist(qx, qy, qz, c[0]);
     int lj = 0;
 #pragma unroll
@@ -350,6 +361,7 @@ __device__ __forceinline__ void scan_global_outward(const PT* __restrict__ tgt, 
     if (nn_better(lb, w + lj, best, pos)) { best = lb; pos = w + lj; }
     ncand += wn;
     ++gsteps;
+    if constexpr (NGICP_WALK_PREFETCH != 0) gsteps += (pf == 0x7fc0beefu) ? 0x100u : 0u;  // (keeps the prefetched word alive until here; gsteps is a diagnostic counter)
     const float lim = fminf(best, gate_sq), dr = (wn == W ? c[W - 1].x : c[kStep - 1].x) - qx, dl = qx - c[0].x;
     const bool more_right = hi < e && !(dr > 0.f && dr * dr + gyz > lim);
     const bool more_left = lo > s && !(dl > 0.f && dl * dl + gyz > lim);
