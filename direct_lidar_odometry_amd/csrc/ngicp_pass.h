@@ -732,8 +732,12 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
   do {                                                                               \
     if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[k] = __builtin_amdgcn_s_memtime(); \
   } while (0)
-  const int done_at_entry = PERSIST ? 0 : st->hot.done;  // (persistent: the blocks left the pass loop when they saw the flag)
-  if (a.dbg_stamps && threadIdx.x == 0 && !done_at_entry) a.dbg_stamps[0] = __builtin_amdgcn_s_memtime();  // (working launches only)
+  // (as a VECTOR load - an atomic load is never made a scalar one: scalar loads return out of order, so the wait for the kernel arguments the
+  // row addresses need would also have waited for this cold word before the first row load could go out.  Persistent: the blocks left
+  // the pass loop when they saw the flag.)
+  const int done_at_entry = PERSIST ? 0 : __hip_atomic_load(&st->hot.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const unsigned long long t_solver_entry = a.dbg_stamps ? __builtin_amdgcn_s_memtime() : 0ull;  // (stored below, once the flag has been looked at:
+                                                                                                 // looking at it HERE put a cold scalar round trip in front of every load of the block)
   // ---- deterministic reduction of the group partials.  Thread = (slot pair vp, group subset sb): it adds the rows
   //      sb, sb + 32, sb + 64, ... of its two slots in increasing order, kSolveChunk sixteen-byte loads in flight per step (one step
   //      covers 1280 groups: the whole c3 grid in a single memory round trip, c5 in two); the 32 subset sums of a slot are then added
@@ -792,6 +796,7 @@ __device__ __forceinline__ void lm_solve_body(const SolveArgs& a, SolveShared<TH
     else oc[k] = (order_it && gi <= last_grp) ? a.grp_cost[gi] : 0;
   }
   if (a.mode == 0 && done_at_entry) return;  // (a scalar load issued at the top: it does not wait for the vector loads above)
+  if (a.dbg_stamps && threadIdx.x == 0) a.dbg_stamps[0] = t_solver_entry;  // (working launches only)
   // The serial lane works on the LDS image of the state in place (a register-resident copy needs ~260 VGPRs: it spills at two
   // waves per SIMD), and wave 0 stores it back with one coalesced pass.
 #pragma unroll
