@@ -220,6 +220,9 @@ __device__ __forceinline__ void knn_search(const Grid& g, const float4* __restri
         const int y = min(max(cy + t % 3 - 1, 0), g.ny - 1), z = min(max(cz + t / 3 - 1, 0), g.nz - 1);  // (rows outside the grid are skipped below)
         bnd[u] = *reinterpret_cast<const Bounds4*>(cell_start + ((z * g.ny + y) * g.nx + cx - 1));
       }
+      // (all five in flight before the first is parked: the compiler had put the fifth load behind the waits for the other four - one more
+      // dependent round trip per query)
+      asm volatile("" ::"v"(bnd[0].v[0]), "v"(bnd[1].v[0]), "v"(bnd[2].v[0]), "v"(bnd[3].v[0]), "v"(bnd[4].v[0]));
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
         const int t = 5 * sub + u;
